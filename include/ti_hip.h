@@ -1,0 +1,145 @@
+/*
+ * ti_hip.h -- C ABI of libti_hip.so, the MI355X (gfx950) sampler hot path for thermodynamic-interpolation.
+ *
+ * The reference (olsson-group/thermodynamic-interpolation) is pure Python and has no FFI seam; the seam this
+ * library sits under is the reference's Python API for the sampling path.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   ti_adw_create / ti_adw_drift      FCNetMultiBeta.__init__/forward      adw/thermo/models/simple.py:11-41
+ *                                     + ODEWrapper.forward                 adw/thermo/models/ode_wrapper.py:30-52
+ *   ti_adw_rollout                    StandardIntegrator.rollout           adw/thermo/integrators.py:33-68
+ *   ti_painn_create / ti_painn_drift  cPaiNN.__init__/forward              mdqm9/thermo/ambient/models/cpainn.py:23-115
+ *                                                                          mdqm9/thermo/latent/models/cpainn.py:23-108
+ *                                     + ODEWrapper.forward/reset_batch     mdqm9/thermo/{ambient,latent}/models/ode_wrapper.py
+ *   ti_painn_rollout                  MoleculeIntegrator.rollout           mdqm9/thermo/ambient/integrators.py:28-68
+ *                                                                          mdqm9/thermo/latent/integrators.py:41-89
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no exceptions cross the ABI.  Every int-returning call returns TI_OK (0) or a
+ *     negative TI_E* code; ti_last_error() returns a thread-local message for the last failure on this thread.
+ *   - The caller owns every buffer it passes.  Weights/graph templates are copied at create(); the handle owns all
+ *     device memory and is freed only by ti_destroy().
+ *   - Buffers marked [host|device] are interpreted according to ti_rollout_desc.mem / the `mem` argument:
+ *     TI_MEM_HOST = ordinary host memory (the library stages through HBM), TI_MEM_DEVICE = pointers into HBM of
+ *     the handle's device (e.g. torch.Tensor.data_ptr()); device work is enqueued on the handle's stream and the
+ *     call returns after that stream has been synchronised.
+ *   - There is no CPU fallback: if no gfx950 device is usable, create() fails with TI_E_HIP.
+ *
+ * Weight layout ("canonical flat layout", fp32 unless noted; every tensor row-major in torch's [out, in] order)
+ *   MLP(f_in, f_h, f_out) := W0[f_h,f_in] b0[f_h] g0[f_h] be0[f_h]  W1[f_h,f_h] b1[f_h] g1[f_h] be1[f_h]  W2[f_out,f_h] b2[f_out]
+ *                            (Linear, LayerNorm(gamma g, beta be, eps 1e-5), SiLU, Linear, LayerNorm, SiLU, Linear;
+ *                             mdqm9/thermo/ambient/models/embedding.py:27-35)
+ *   painn :  edge_emb[4,F]  atom_emb[n_types,F]  MLP(nE*F, F, F)
+ *            L x { phi = MLP(2F,F,5F)  w = MLP(F,F,5F)  U[F,F]  V[F,F]  upd = MLP(2F,F,3F) }
+ *            readout MLP(F,F,2)  Vr[1,F]
+ *            nE = 4 (ambient: atom|T0|T1|t), 3 (latent multi-T: atom|T|t), 2 (latent single-T: atom|t)
+ *   adw   :  beta_embed: W[H,3] b[H] W[H,H] b[H] W[1,H] b[1] ;  net: W[H,3] b[H] (W[H,H] b[H]) x (num_layers-1) W[1,H] b[1]
+ *            passed as fp64 (the reference trains/saves in float64, adw/train.py:29); the device computes in fp32.
+ */
+#ifndef TI_HIP_H
+#define TI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TI_ABI_VERSION 1
+
+enum { TI_OK = 0, TI_E_ARG = -1, TI_E_HIP = -2, TI_E_NAN = -3, TI_E_ALLOC = -4, TI_E_UNSUPPORTED = -5 };
+enum { TI_MEM_HOST = 0, TI_MEM_DEVICE = 1 };
+enum { TI_VARIANT_AMBIENT = 0, TI_VARIANT_LATENT_MULTI = 1, TI_VARIANT_LATENT_SINGLE = 2 };
+/* Fixed-step schemes on a caller-supplied grid t[0..n_step-1] (the reference passes torch.linspace(start,end,n_step),
+ * integrators.py:43; reversed grid for reverse_ode).  Build-defined (SURVEY.md F3 / §8a row I-new):
+ *   EULER: x_{k+1} = x_k + dt_k b(x_k,t_k)                  (== torchdiffeq method='euler' on that grid)
+ *   HEUN : xp = x_k + dt_k b(x_k,t_k); x_{k+1} = x_k + dt_k/2 (b(x_k,t_k) + b(xp,t_{k+1}))
+ *   EM   : x_{k+1} = x_k + dt_k b(x_k,t_k) + sqrt(2 eps |dt_k|) xi,  xi ~ N(0,1) from Philox4x32-10 keyed by
+ *          (seed, global trajectory id, step, component); eps = 0 reproduces EULER bit-for-bit. */
+enum { TI_SCHEME_EULER = 0, TI_SCHEME_HEUN = 1, TI_SCHEME_EM = 2 };
+
+typedef struct ti_handle ti_handle;
+
+typedef struct ti_painn_desc {
+    int32_t variant;        /* TI_VARIANT_* */
+    int32_t n_features;     /* F: multiple of 32, <= 256 */
+    int32_t n_layers;       /* L = score_layers */
+    int32_t n_types;        /* rows of the atom embedding (reference: 25) */
+    int32_t n_atoms;        /* A atoms per molecule (every molecule of a batch shares one species) */
+    int32_t n_edges;        /* E_m directed edges per molecule */
+    float   temp_length;    /* PositionalEncoder max_length for temperatures */
+    float   time_length;    /* ... for t (reference: 10) */
+    float   length_scale;   /* ... for edge distances (reference: 10) */
+    float   temp_mean;      /* mean(temperatures)            (embedding.py:209) */
+    float   temp_range;     /* max(temperatures) - min(...)  (embedding.py:210) */
+} ti_painn_desc;
+
+typedef struct ti_adw_desc {
+    int32_t hidden_size;    /* H: multiple of 32, <= 256 */
+    int32_t num_layers;     /* number of hidden layers of `net` (reference: 5) */
+} ti_adw_desc;
+
+typedef struct ti_rollout_desc {
+    int32_t scheme;         /* TI_SCHEME_* */
+    int32_t n_step;         /* number of grid points; n_step-1 steps are taken */
+    int32_t save_every;     /* k>=1: rows 0,k,2k,... of the path plus the final state are written; 0: final state only */
+    int32_t mem;            /* TI_MEM_* for x0 / cond / out_path */
+    float   eps;            /* EM noise scale (>= 0) */
+    int32_t com_free_noise; /* EM, molecules: remove the per-molecule centre of mass of xi */
+    uint64_t seed;          /* EM Philox key */
+    int64_t traj_offset;    /* global index of trajectory 0 of this call (multi-GPU shards keep RNG independent of the split) */
+    const float* t_grid;    /* [n_step] host memory */
+} ti_rollout_desc;
+
+/* number of path rows ti_*_rollout writes for (n_step, save_every) */
+int64_t ti_rollout_rows(int32_t n_step, int32_t save_every);
+
+int ti_version(void);
+int ti_device_count(void);
+const char* ti_last_error(void);
+
+/* ---- adw: 1-D asymmetric double well ------------------------------------------------------------------------ */
+ti_handle* ti_adw_create(const ti_adw_desc* desc, const double* weights, size_t n_weights, int device);
+/* b[i] = net([x_i, t, beta_embed([beta0_i, beta1_i, t])]);  x,beta0,beta1,out: [B] fp32 [host|device] */
+int ti_adw_drift(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out, int mem);
+/* out_path: [rows, B] fp32 with rows = ti_rollout_rows(...) */
+int ti_adw_rollout(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* beta0, const float* beta1,
+                   int64_t B, float* out_path, int64_t* n_fevals);
+
+/* ---- mdqm9: cPaiNN drift over homogeneous molecule batches ------------------------------------------------------ */
+/* edge_src/edge_dst: [E_m] local atom indices of ONE molecule in the reference's (src,dst)-sorted order
+ * (edge_index[0]=src, edge_index[1]=dst: messages flow src -> dst, cpainn.py:273-304); edge_type: [E_m] in 0..3;
+ * atom_ids: [A] rows of the atom embedding (reference: arange(A), mdqm9_ambient.py:219-220). */
+ti_handle* ti_painn_create(const ti_painn_desc* desc, const float* weights, size_t n_weights,
+                           const int32_t* edge_src, const int32_t* edge_dst, const int32_t* edge_type,
+                           const int32_t* atom_ids, int device);
+/* x: [B,A,3]; cond: [B,A,n_cond] per-node conditioning (ambient: T0,T1; latent multi-T: T; single-T: NULL); out: [B,A,3] */
+int ti_painn_drift(ti_handle* h, const float* x, float t, const float* cond, int64_t B, float* out, int mem);
+/* out_path: [rows, B, A, 3] */
+int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* cond, int64_t B,
+                     float* out_path, int64_t* n_fevals);
+
+/* ---- shared ------------------------------------------------------------------------------------------------------ */
+void ti_destroy(ti_handle* h);
+/* Run on an external HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream); NULL restores the
+ * handle's own stream. */
+int ti_set_stream(ti_handle* h, void* hip_stream);
+/* Pre-size the HBM workspace for batches up to B trajectories (otherwise grown on demand). */
+int ti_reserve(ti_handle* h, int64_t B);
+/* Live kernel timing with HIP events on the handle's stream (bench.py roofline leg). */
+enum { TI_KERNEL_PAINN_EDGE = 0, TI_KERNEL_PAINN_UPDATE = 1, TI_KERNEL_PAINN_EMBED = 2, TI_KERNEL_PAINN_READOUT = 3,
+       TI_KERNEL_ADW = 4, TI_KERNEL_INTEGRATE = 5, TI_KERNEL_COUNT = 6 };
+int ti_profile_enable(ti_handle* h, int on);
+int ti_profile_read(ti_handle* h, int kernel, int64_t* n_launches, double* total_ms);   /* also resets that slot */
+/* Debug taps for parity tests: copy an intermediate of the LAST ti_painn_drift call to host.
+ * what: 0 = s [B,A,F], 1 = v [B,A,3,F] (component-major planes), 2 = e (row-major [B,E_m,F], edges in (dst,src) order). */
+int ti_painn_debug_tap(ti_handle* h, int stop_after_stage);   /* stage = 0 embed, 1+2l message l, 2+2l update l; -1 = off */
+int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats);
+/* Device self-test of the MFMA operand/accumulator lane maps the kernels rely on. */
+int ti_selftest(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TI_HIP_H */

@@ -1,0 +1,109 @@
+"""The CPU oracle (oracle/ti_oracle.c) against golden vectors produced by the reference's own PyTorch modules
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU parity tests then use the oracle as checker."""
+import numpy as np
+import pytest
+
+from conftest import golden_weights, load_golden, pkg, rel_l2
+from oracle import oracle
+
+PAINN_CASES = ["ambient_small", "ambient_sparse", "ambient_a9", "ambient_a25", "ambient_full", "ambient_ctor", "ambient_b1",
+               "latent_multi", "latent_single", "latent_full", "latent_ctor"]
+# fp32 tolerance.  SURVEY.md §8c proposed 1e-6, but the reference's own fp32 forward sits 0.4e-6 (F=32) to 6e-6
+# (latent, F=128, unit-variance coordinates) away from exact arithmetic (the oracle's fp64 mode) because of GEMM summation
+# order and sin/cos of large arguments; two fp32 evaluations cannot agree better than that.  So: below the north-star bar
+# (1e-5) and within 3x of the reference's own distance to exact arithmetic.
+TOL_BAR = 1e-5
+
+
+def close_f32(err32, err64):
+    return err32 < TOL_BAR and err32 < 3.0 * max(err64, 5e-7)
+
+
+def make_oracle(g):
+    return oracle.PainnOracle(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                              g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"])
+
+
+@pytest.mark.parametrize("name", PAINN_CASES)
+def test_painn_drift_matches_reference(name):
+    g = load_golden(name)
+    o = make_oracle(g)
+    for i, t in enumerate(g["ts"]):
+        got = o.drift(g["x"], float(t), g["cond"])
+        got64 = o.drift(g["x"], float(t), g["cond"], precision=64)
+        e32, e64 = rel_l2(got, g[f"drift_{i}"]), rel_l2(got64, g[f"drift_{i}"])
+        assert e64 < TOL_BAR, (name, i, e64)                  # reference fp32 round-off vs exact arithmetic
+        assert close_f32(e32, e64), (name, i, e32, e64)
+
+
+@pytest.mark.parametrize("name", ["ambient_small", "ambient_sparse", "latent_multi"])
+def test_painn_intermediates_match_reference(name):
+    g = load_golden(name)
+    o = make_oracle(g)
+    B, A, F, L = int(g["B"]), int(g["A"]), int(g["F"]), int(g["L"])
+    t = float(g["ts"][1])
+    stages = [(0, "embed")] + [(1 + 2 * l, f"msg{l}") for l in range(L)] + [(2 + 2 * l, f"upd{l}") for l in range(L)]
+    for stage, tag in stages:
+        _, taps = o.drift(g["x"], t, g["cond"], tap_stage=stage)
+        if tag == "embed":
+            assert rel_l2(taps["s"].reshape(B * A, F), g["im::s_embed"]) < 3e-6
+            continue
+        assert rel_l2(taps["s"].reshape(B * A, F), g[f"im::s_{tag}"]) < 3e-6, tag
+        assert rel_l2(taps["v"].reshape(B * A, F, 3), g[f"im::v_{tag}"]) < 2e-6, tag
+        if tag.startswith("msg"):
+            assert rel_l2(taps["e"].reshape(-1, F), g[f"im::e_{tag}"]) < 3e-6, tag
+
+
+@pytest.mark.parametrize("name", ["ambient_small", "ambient_a9", "ambient_full", "latent_multi"])
+@pytest.mark.parametrize("scheme", ["euler", "heun"])
+def test_painn_fixed_step_trajectory(name, scheme):
+    g = load_golden(name)
+    o = make_oracle(g)
+    path, nfe = o.rollout(g["x"], g["cond"], g["traj_grid"], scheme=scheme, save_every=1)
+    ref = g[f"traj_{scheme}"]
+    assert path.shape == ref.shape
+    assert nfe == (len(g["traj_grid"]) - 1) * (2 if scheme == "heun" else 1)
+    assert rel_l2(path - path[0], ref - ref[0]) < 5e-6      # displacement, not the (dominant) initial coordinates
+    # save_every=0 returns only the end state; save_every=4 keeps rows 0,4,8,... plus the last
+    last, _ = o.rollout(g["x"], g["cond"], g["traj_grid"], scheme=scheme, save_every=0)
+    np.testing.assert_array_equal(last[0], path[-1])
+    sub, _ = o.rollout(g["x"], g["cond"], g["traj_grid"], scheme=scheme, save_every=4)
+    n = len(g["traj_grid"])
+    rows = list(range(0, n, 4)) + ([n - 1] if (n - 1) % 4 else [])
+    np.testing.assert_array_equal(sub, path[rows])
+
+
+def test_em_eps0_is_euler_and_noise_is_standard_normal():
+    g = load_golden("ambient_small")
+    o = make_oracle(g)
+    e, _ = o.rollout(g["x"], g["cond"], g["traj_grid"], scheme="euler")
+    em, _ = o.rollout(g["x"], g["cond"], g["traj_grid"], scheme="em", eps=0.0, seed=3)
+    np.testing.assert_array_equal(e, em)
+    z = np.array([oracle.normal(7, tr, st, c) for tr in range(40) for st in range(10) for c in range(54)])
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    # counter-based: same key -> same value, different trajectory -> different stream
+    assert oracle.normal(7, 5, 3, 2) == oracle.normal(7, 5, 3, 2) != oracle.normal(7, 6, 3, 2)
+
+
+def adw_oracle(g):
+    ti = pkg()
+    H, nl = int(g["hidden"]), int(g["num_layers"])
+    spec = ti.weights.adw_param_spec(H, nl)
+    sd = {k[4:]: v for k, v in g.items() if k.startswith("sd::")} or ti.synthetic.adw_state_dict(H, nl, int(g["seed"]))
+    return oracle.AdwOracle(H, nl, ti.weights.flatten_state_dict(sd, spec, dtype=np.float64))
+
+
+@pytest.mark.parametrize("name", ["adw_h256", "adw_ctor_h64"])
+def test_adw_drift_and_trajectory(name):
+    g = load_golden(name)
+    o = adw_oracle(g)
+    for tag in ("", "_var"):
+        b0, b1 = g["beta0" + tag], g["beta1" + tag]
+        for i, t in enumerate(g["ts"]):
+            got = o.drift(g["x"].astype(np.float64), float(t), b0, b1)
+            assert rel_l2(got, g[f"drift{tag}_{i}"]) < 1e-12, (tag, i)          # fp64 vs fp64 reference
+            got32 = o.drift(g["x"], float(t), b0, b1, precision=32)
+            assert rel_l2(got32, g[f"drift{tag}_{i}"]) < 1e-5, (tag, i)         # fp32 arithmetic vs fp64 reference
+    for scheme in ("euler", "heun"):
+        path, _ = o.rollout(g["x"].astype(np.float64), g["beta0"], g["beta1"], g["traj_grid"], scheme=scheme)
+        assert rel_l2(path, g[f"traj_{scheme}"]) < 1e-12

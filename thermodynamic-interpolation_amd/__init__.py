@@ -1,0 +1,6 @@
+"""MI355X-native sampler hot path for thermodynamic-interpolation.
+
+The directory name is fixed by the build contract and is not a Python identifier; import it with
+``importlib.import_module("thermodynamic-interpolation_amd")`` (tests/conftest.py and __graft_entry__.py do).
+"""
+from . import weights, synthetic  # noqa: F401
