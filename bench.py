@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""bench.py -- integration-steps/sec of the mdqm9 ambient sampler hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json north_star / configs[3] shape): 65 536 trajectories per GPU of an 18-atom fully connected
+molecule, ambient cPaiNN drift F=128 / L=5 (random-init weights of that architecture, synthetic coordinates), T0 = 1000 K,
+T1 round-robin over the 6-rung ladder, Euler-Maruyama steps (eps = 0.01) on the reference grid.  A "step" is one
+integrator step of every trajectory of the batch = one drift evaluation + the fused state update.  Trajectories are
+independent, so ranks shard them with no data-path collective ("weak" scaling: per-GPU batch fixed); the only
+collective is the final RCCL all-gather of the end states, which is inside the timed region.
+
+Inputs are resident in HBM before the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F, L, A = 128, 5, 18
+E_M = A * (A - 1)
+FLOP_PER_MOL_EVAL = F * F * (L * (30 * E_M + 24 * A) + (2 * 4 + 4) * A + 4 * A) + 10 * F * A      # 7.9216e8
+FLOP_PER_EDGE_LAYER = 30 * F * F
+PEAK_F32_MFMA_TFLOPS = 157.3                                                                      # MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--eps", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="molecules in the CPU-oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(ti, flat, template, sample_mols, steps=4):
+    """The CPU oracle (oracle/ti_oracle.c, OpenMP) on a bounded sample of the same workload; rank 0, N=1 only."""
+    from oracle import oracle
+    src, dst, et = template
+    orc = oracle.PainnOracle(ti.weights.AMBIENT, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+    x, cond = ti.synthetic.molecule_coords(sample_mols, A, 1), ti.synthetic.ambient_cond(sample_mols, A)
+    grid = ti.engine.time_grid(0.0, 1.0, 1001)[:steps + 1]
+    orc.drift(x[:16], 0.0, cond[:16])                     # warm-up (thread pool, page-in)
+    t0 = time.perf_counter()
+    orc.rollout(x, cond, grid, scheme="em", save_every=0, eps=0.01, seed=0)
+    dt = time.perf_counter() - t0
+    return {"value": sample_mols * steps / dt, "unit": "integration-steps/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{sample_mols} molecules x {steps} Euler-Maruyama steps, same F/L/A/graph, OpenMP over molecules, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the sampling path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ti = importlib.import_module("thermodynamic-interpolation_amd")
+    syn, W = ti.synthetic, ti.weights
+    template = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 0), W.painn_param_spec(W.AMBIENT, F, L, 25))
+    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *template, np.arange(A), flat, temp_length=100.0, device=local_rank)
+    B = args.batch
+    eng.reserve(B)
+    # synthetic inputs, resident in HBM; rank r owns global trajectories [r*B, (r+1)*B)
+    x0 = torch.from_numpy(syn.molecule_coords(B, A, seed=rank)).to(dev)
+    cond = torch.from_numpy(syn.ambient_cond(B, A)).to(dev)
+    out = torch.empty((1, B, A, 3), dtype=torch.float32, device=dev)
+    grid = ti.engine.time_grid(0.0, 1.0, 1001)            # config 4: 1000-step grid; we time K of its steps
+    gathered = [torch.empty_like(out[0]) for _ in range(world)] if world > 1 else None
+
+    def run(k_steps, first_step):
+        eng.rollout(x0, cond, grid[first_step:first_step + k_steps + 1], scheme="em", eps=args.eps, seed=1234,
+                    traj_offset=rank * B, save_every=0, out=out)
+        if world > 1:
+            dist.all_gather(gathered, out[0])             # the only collective: final gather of the samples (RCCL)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup, 0)
+    sync()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    sync()
+    elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    n_edge, ms_edge = eng.profile_read("painn_edge")
+    n_upd, ms_upd = eng.profile_read("painn_update")
+    assert bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        edge_ms = ms_edge / max(n_edge, 1)
+        achieved = B * E_M * FLOP_PER_EDGE_LAYER / (edge_ms * 1e-3) / 1e12 if n_edge else None
+        rec = {
+            "metric": "integration-steps/sec (whole node)", "value": value, "unit": "trajectory-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "mdqm9 ambient sampler: 65536 molecules/GPU x 18 atoms (fully connected, 306 edges), cPaiNN F=128 L=5, "
+                                   "Euler-Maruyama steps of the 1000-step grid, T1 over a 6-rung ladder",
+                       "trajectories_per_gpu": B, "atoms": A, "n_features": F, "score_layers": L, "scheme": "em", "eps": args.eps,
+                       "sharding": f"dp{world} over independent trajectories, final RCCL all-gather of end states"},
+            "whole_step_tflops": FLOP_PER_MOL_EVAL * B * args.steps * world / elapsed / 1e12,
+            "roofline": {"kernel": "painn_edge_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, "traffic": None,
+                         "launches": n_edge, "avg_launch_ms": edge_ms, "update_kernel_avg_ms": ms_upd / max(n_upd, 1),
+                         "flops_per_launch": B * E_M * FLOP_PER_EDGE_LAYER},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(ti, flat, template, args.cpu_sample)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference golden vectors and the CPU oracle.
+
+Tolerances (stated once):
+  DRIFT_TOL = 1e-5 rel-L2  -- the north-star bar for the fp32 drift vs the reference CPU path (BASELINE.json).
+  Observed values are ~1-3e-6, the fp32 round-off floor of the reference itself (tests/test_oracle_golden.py).
+Everything here needs a real MI355X: `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_weights, load_golden, pkg, rel_l2
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+DRIFT_TOL = 1e-5
+PAINN_CASES = ["ambient_small", "ambient_sparse", "ambient_a9", "ambient_a25", "ambient_full", "ambient_ctor", "ambient_b1",
+               "latent_multi", "latent_single", "latent_full", "latent_ctor"]
+
+
+def engine_from_golden(g, device=0):
+    ti = pkg()
+    return ti.engine.PainnEngine(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                                 g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"],
+                                 device=device)
+
+
+def oracle_from_golden(g):
+    return oracle.PainnOracle(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                              g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"])
+
+
+def test_mfma_lane_map_selftest():
+    pkg().engine.selftest(0)
+
+
+@pytest.mark.parametrize("name", PAINN_CASES)
+def test_painn_drift_vs_reference_golden(name):
+    g = load_golden(name)
+    eng = engine_from_golden(g)
+    for i, t in enumerate(g["ts"]):
+        got = eng.drift(g["x"], float(t), g["cond"])
+        err = rel_l2(got, g[f"drift_{i}"])
+        assert np.isfinite(got).all()
+        assert err < DRIFT_TOL, (name, i, err)
+
+
+@pytest.mark.parametrize("name", ["ambient_small", "ambient_sparse", "latent_multi"])
+def test_painn_stage_taps_vs_oracle_and_golden(name):
+    """s, v, e after the embed stage and after every message / update block."""
+    g = load_golden(name)
+    eng, orc = engine_from_golden(g), oracle_from_golden(g)
+    B, A, F, L = int(g["B"]), int(g["A"]), int(g["F"]), int(g["L"])
+    t = float(g["ts"][1])
+    stages = [(0, "embed")] + [s for l in range(L) for s in ((1 + 2 * l, f"msg{l}"), (2 + 2 * l, f"upd{l}"))]
+    try:
+        for stage, tag in stages:
+            eng.debug_tap(stage)
+            eng.drift(g["x"], t, g["cond"])
+            _, taps = orc.drift(g["x"], t, g["cond"], tap_stage=stage)
+            s = eng.debug_read("s", B)
+            assert rel_l2(s, taps["s"]) < DRIFT_TOL, (tag, "s")
+            if tag == "embed":
+                assert rel_l2(s.reshape(B * A, F), g["im::s_embed"]) < DRIFT_TOL
+                continue
+            v = eng.debug_read("v", B).transpose(0, 1, 3, 2)          # [B,A,3,F] -> reference [B,A,F,3]
+            assert rel_l2(v, taps["v"]) < DRIFT_TOL, (tag, "v")
+            assert rel_l2(v.reshape(B * A, F, 3), g[f"im::v_{tag}"]) < DRIFT_TOL, (tag, "v golden")
+            assert rel_l2(s.reshape(B * A, F), g[f"im::s_{tag}"]) < DRIFT_TOL, (tag, "s golden")
+            if tag.startswith("msg") and int(tag[3:]) < L - 1:       # the last message block's edge update is dead code
+                e = eng.debug_read("e", B)
+                assert rel_l2(e, taps["e"]) < DRIFT_TOL, (tag, "e")
+                assert rel_l2(e.reshape(-1, F), g[f"im::e_{tag}"]) < DRIFT_TOL, (tag, "e golden")
+    finally:
+        eng.debug_tap(-1)
+    # taps off again: a normal evaluation still matches
+    assert rel_l2(eng.drift(g["x"], t, g["cond"]), g["drift_1"]) < DRIFT_TOL
+
+
+@pytest.mark.parametrize("name", ["ambient_small", "ambient_a9", "ambient_full", "latent_multi"])
+@pytest.mark.parametrize("scheme", ["euler", "heun"])
+def test_painn_rollout_vs_reference_trajectory(name, scheme):
+    g = load_golden(name)
+    eng = engine_from_golden(g)
+    path, nfe = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme=scheme, save_every=1)
+    ref = g[f"traj_{scheme}"]
+    assert path.shape == ref.shape
+    assert nfe == (len(g["traj_grid"]) - 1) * (2 if scheme == "heun" else 1)
+    np.testing.assert_array_equal(path[0], g["x"])
+    assert rel_l2(path - path[0], ref - ref[0]) < 2e-5        # accumulated over the steps; per-step drift bar is 1e-5
+    last, _ = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme=scheme, save_every=0)
+    np.testing.assert_array_equal(last[0], path[-1])           # deterministic: bit-identical re-run
+    sub, _ = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme=scheme, save_every=4)
+    n = len(g["traj_grid"])
+    rows = list(range(0, n, 4)) + ([n - 1] if (n - 1) % 4 else [])
+    np.testing.assert_array_equal(sub, path[rows])
+
+
+def test_em_eps0_is_euler_bit_for_bit_and_noise_matches_oracle():
+    g = load_golden("ambient_small")
+    eng, orc = engine_from_golden(g), oracle_from_golden(g)
+    e, _ = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme="euler")
+    em0, _ = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme="em", eps=0.0, seed=11)
+    np.testing.assert_array_equal(e, em0)
+    for com in (False, True):
+        em, _ = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme="em", eps=0.05, seed=11, traj_offset=5, com_free_noise=com)
+        ref, _ = orc.rollout(g["x"], g["cond"], g["traj_grid"], scheme="em", eps=0.05, seed=11, traj_offset=5, com_free_noise=int(com))
+        assert rel_l2(em - em[0], ref - ref[0]) < 1e-4           # same Philox stream; libm differences in Box-Muller
+        if com:     # one step: x_em - x_euler = sigma * (xi - COM(xi)) has no centre-of-mass component
+            np.testing.assert_allclose((em[1] - e[1]).mean(axis=1), 0.0, atol=1e-6)
+    # RNG is keyed by the global trajectory id: a shard starting at trajectory 1 reproduces rows 1.. of the full batch
+    full, _ = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme="em", eps=0.05, seed=3)
+    part, _ = eng.rollout(g["x"][1:], g["cond"][1:], g["traj_grid"], scheme="em", eps=0.05, seed=3, traj_offset=1)
+    np.testing.assert_array_equal(full[:, 1:], part)
+
+
+@pytest.mark.parametrize("F,L,A,B,variant", [(64, 2, 18, 37, 0), (128, 2, 18, 130, 0), (256, 2, 25, 9, 1), (32, 5, 3, 200, 2), (128, 1, 2, 5, 0)])
+def test_painn_ragged_batches_vs_oracle(F, L, A, B, variant):
+    """Batch sizes that are not multiples of the molecule-group size or of the 32-row tiles; F = 64 and 256 paths."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(variant, F, L, 25, seed=F + A), W.painn_param_spec(variant, F, L, 25))
+    x = syn.molecule_coords(B, A, seed=B)
+    cond = [syn.ambient_cond(B, A), syn.latent_cond(B, A, 500.0), None][variant]
+    kw = dict(temp_length=100.0 if variant == 0 else 75.0)
+    eng = ti.engine.PainnEngine(variant, F, L, A, src, dst, et, np.arange(A), flat, **kw)
+    orc = oracle.PainnOracle(variant, F, L, A, src, dst, et, np.arange(A), flat, **kw)
+    got = eng.drift(x, 0.37, cond)
+    assert rel_l2(got, orc.drift(x, 0.37, cond)) < DRIFT_TOL
+    # the same engine re-used with a smaller and a larger batch (workspace regrowth)
+    for b2 in (1, B + 77):
+        x2 = syn.molecule_coords(b2, A, seed=b2)
+        c2 = [syn.ambient_cond(b2, A), syn.latent_cond(b2, A, 500.0), None][variant]
+        assert rel_l2(eng.drift(x2, 0.9, c2), orc.drift(x2, 0.9, c2)) < DRIFT_TOL
+
+
+def test_painn_large_batch_properties():
+    """BASELINE-size features (F=128, L=5, A=18) on a batch the oracle cannot finish quickly: size-independent
+    properties of the architecture -- rotation equivariance, translation invariance, independence of molecules, determinism."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    F, L, A, B = 128, 5, 18, 4096
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=0), W.painn_param_spec(0, F, L, 25))
+    eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+    x, cond = syn.molecule_coords(B, A, seed=0), syn.ambient_cond(B, A)
+    b = eng.drift(x, 0.5, cond)
+    assert np.isfinite(b).all()
+    np.testing.assert_array_equal(b, eng.drift(x, 0.5, cond))                       # deterministic
+    q, _ = np.linalg.qr(np.random.RandomState(1).standard_normal((3, 3)))
+    q = (q * np.sign(np.linalg.det(q))).astype(np.float32)                          # proper rotation (the cross-product channel is chiral)
+    assert rel_l2(eng.drift(x @ q.T, 0.5, cond), b @ q.T) < DRIFT_TOL
+    assert rel_l2(eng.drift(x + np.float32([0.3, -0.2, 0.1]), 0.5, cond), b) < DRIFT_TOL
+    perm = np.random.RandomState(2).permutation(B)
+    # molecules are independent; the position inside a molecule group only changes the order of a few partial sums
+    assert rel_l2(eng.drift(x[perm], 0.5, cond[perm]), b[perm]) < 5e-6
+    # a slice of the batch evaluated on its own agrees bit for bit (group/tile padding does not leak)
+    np.testing.assert_array_equal(eng.drift(x[:131], 0.5, cond[:131]), b[:131])
+    orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+    idx = np.r_[0:3, B - 3:B]
+    assert rel_l2(b[idx], orc.drift(x[idx], 0.5, cond[idx])) < DRIFT_TOL
+
+
+# ----------------------------------------------------------------------------------------------------------- adw
+def adw_engine(g):
+    ti = pkg()
+    H, nl = int(g["hidden"]), int(g["num_layers"])
+    spec = ti.weights.adw_param_spec(H, nl)
+    sd = {k[4:]: v for k, v in g.items() if k.startswith("sd::")} or ti.synthetic.adw_state_dict(H, nl, int(g["seed"]))
+    flat = ti.weights.flatten_state_dict(sd, spec, dtype=np.float64)
+    return ti.engine.AdwEngine(H, nl, flat), oracle.AdwOracle(H, nl, flat)
+
+
+@pytest.mark.parametrize("name", ["adw_h256", "adw_ctor_h64"])
+def test_adw_drift_and_rollout_vs_reference(name):
+    g = load_golden(name)
+    eng, orc = adw_engine(g)
+    for tag in ("", "_var"):
+        b0, b1 = g["beta0" + tag].astype(np.float32), g["beta1" + tag].astype(np.float32)
+        for i, t in enumerate(g["ts"]):
+            got = eng.drift(g["x"], float(t), b0, b1)
+            assert rel_l2(got, g[f"drift{tag}_{i}"]) < DRIFT_TOL, (tag, i)          # fp32 device vs fp64 reference
+    b0, b1 = g["beta0"].astype(np.float32), g["beta1"].astype(np.float32)
+    for scheme in ("euler", "heun"):
+        path, nfe = eng.rollout(g["x"], b0, b1, g["traj_grid"], scheme=scheme)
+        ref = g[f"traj_{scheme}"]
+        assert path.shape == ref.shape
+        assert rel_l2(path - path[0], ref - ref[0]) < 2e-5
+    e, _ = eng.rollout(g["x"], b0, b1, g["traj_grid"], scheme="euler")
+    em0, _ = eng.rollout(g["x"], b0, b1, g["traj_grid"], scheme="em", eps=0.0, seed=5)
+    np.testing.assert_array_equal(e, em0)
+    em, _ = eng.rollout(g["x"], b0, b1, g["traj_grid"], scheme="em", eps=0.1, seed=5)
+    ref, _ = orc.rollout(g["x"].astype(np.float64), b0, b1, g["traj_grid"], scheme="em", eps=0.1, seed=5)
+    assert rel_l2(em, ref) < 1e-4
+
+
+def test_adw_large_batch_vs_oracle():
+    ti = pkg()
+    flat = ti.weights.flatten_state_dict(ti.synthetic.adw_state_dict(256, 5, 0), ti.weights.adw_param_spec(256, 5), dtype=np.float64)
+    eng, orc = ti.engine.AdwEngine(256, 5, flat), oracle.AdwOracle(256, 5, flat)
+    B = 10_007
+    x = ti.synthetic.adw_x0(B, 3)
+    b0, b1 = np.full(B, 1.0, np.float32), np.full(B, 1.25, np.float32)
+    assert rel_l2(eng.drift(x, 0.4, b0, b1), orc.drift(x.astype(np.float64), 0.4, b0, b1)) < DRIFT_TOL
+
+
+# ------------------------------------------------------------------------------------------------- device buffers
+def test_device_resident_buffers_match_host_path():
+    torch = pytest.importorskip("torch")
+    g = load_golden("ambient_a9")
+    eng = engine_from_golden(g)
+    host, _ = eng.rollout(g["x"], g["cond"], g["traj_grid"], scheme="heun")
+    xd, cd = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["cond"]).cuda()
+    dev, _ = eng.rollout(xd, cd, g["traj_grid"], scheme="heun")
+    assert dev.is_cuda
+    np.testing.assert_array_equal(dev.cpu().numpy(), host)
+    np.testing.assert_array_equal(eng.drift(xd, 0.25, cd).cpu().numpy(), eng.drift(g["x"], 0.25, g["cond"]))

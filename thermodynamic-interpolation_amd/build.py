@@ -1,0 +1,55 @@
+"""Builds libti_hip.so (gfx950) in-tree with hipcc.  `python -m` style entry: build(force=False, jobs=3)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libti_hip.so")
+SOURCES = ["ti_api.hip", "painn_kernels.hip", "adw_kernels.hip"]
+HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm to build libti_hip.so)")
+    return exe
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, jobs: int = 3, verbose: bool = False) -> str:
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    if not force and not _stale(SO, deps):
+        return SO
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(obj, [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]):
+            cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs])
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,190 @@
+// adw_kernels.hip -- FCNetMultiBeta drift (adw double well) on gfx950, plus the elementwise integrator kernels.
+//
+// Restates /root/reference/adw/thermo/models/simple.py:22-41.  Both MLPs of the model have the same shape
+//   Linear(3 -> H), SiLU, [Linear(H -> H), SiLU] x n_hidden, Linear(H -> 1)
+// (beta_embed: inputs [beta0, beta1, t], n_hidden = 1;  net: inputs [x, t, beta_embed], n_hidden = num_layers-1),
+// so one kernel serves both: 32 rows per wave, hidden activations in registers, H x H layers on the f32 MFMA.
+#include "mfma_chain.hpp"
+#include "ti_internal.hpp"
+
+namespace ti {
+
+template <int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void adw_mlp_kernel(const AdwParams p)
+{
+    constexpr int H = 32 * NB, T = 64 * WAVES, CH4 = 256 * NB;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    Pipe<NB, T> pipe;
+    if (p.nch > 0) pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);
+    (void)CH4;
+    const long long row = ((long long)blockIdx.x * WAVES + wave) * 32 + j;
+    const bool ok = row < p.B;
+    const long long r = ok ? row : p.B - 1;
+    const float a0 = p.x[r];
+    const float a1 = p.in1 ? p.in1[r] : p.t;
+    const float a2 = p.idx ? p.emb[p.idx[r]] : (p.emb ? p.emb[r] : p.t);
+
+    // input layer (K = 3): plain FMAs straight into the register layout
+    Act<NB> cur;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const f32x16 b = load_block(p.b_in, nb, h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* w = p.w_in + (32 * nb + 8 * g + 4 * h) * 3;      // rows f..f+3 of W_in[H][3]
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 4),
+                        w2 = *reinterpret_cast<const f32x4*>(w + 8);
+            const float ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cur.b[nb][4 * g + q] = silu(fmaf(ww[3 * q + 2], a2, fmaf(ww[3 * q + 1], a1, fmaf(ww[3 * q], a0, b[4 * g + q]))));
+        }
+    }
+    // hidden layers
+    for (int l = 0; l < p.n_hidden; ++l) {
+        Act<NB> nxt;
+        const float* bias = p.b_hidden + (size_t)l * H;
+#pragma unroll
+        for (int nbo = 0; nbo < NB; ++nbo) {
+            const f32x4* wl = pipe.begin();
+            f32x16 a = load_block(bias, nbo, h);
+            gemm_bt(a, cur, wl, lane);
+            pipe.end();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nxt.b[nbo][i] = silu(a[i]);
+        }
+        cur = nxt;
+    }
+    const float o = dot_set(cur, p.w_out, h) + p.b_out;
+    if (ok && h == 0) p.out[row] = o;
+}
+
+#define TI_DISPATCH_NB(NBv, ...) \
+    switch (NBv) {                                                            \
+        case 1: { constexpr int NB = 1, WAVES = 8; __VA_ARGS__; } break;             \
+        case 2: { constexpr int NB = 2, WAVES = 8; __VA_ARGS__; } break;             \
+        case 4: { constexpr int NB = 4, WAVES = 8; __VA_ARGS__; } break;             \
+        case 8: { constexpr int NB = 8, WAVES = 4; __VA_ARGS__; } break;             \
+        default: return hipErrorInvalidValue;                                 \
+    }
+
+hipError_t configure_adw_kernels(int NBv)
+{
+    TI_DISPATCH_NB(NBv, {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(adw_mlp_kernel<NB, WAVES>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * NB * 16);
+    });
+    return hipSuccess;
+}
+
+hipError_t launch_adw(int NBv, const AdwParams& p, hipStream_t st)
+{
+    TI_DISPATCH_NB(NBv, {
+        const dim3 g((unsigned)((p.B + 32LL * WAVES - 1) / (32LL * WAVES)));
+        hipLaunchKernelGGL((adw_mlp_kernel<NB, WAVES>), g, dim3(64 * WAVES), 2 * 256 * NB * 16, st, p);
+    });
+    return hipGetLastError();
+}
+
+// ================================================================================================== integrator
+// Unfused multiply/add on purpose: the reference state update is `x + dt * b` in two roundings.
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, const float* __restrict__ b, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = __fadd_rn(x[i], __fmul_rn(a, b[i]));
+}
+__global__ void heun_kernel(float* __restrict__ x, float hdt, const float* __restrict__ b1, const float* __restrict__ b2, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = __fadd_rn(x[i], __fmul_rn(hdt, __fadd_rn(b1[i], b2[i])));
+}
+
+// Philox4x32-10, same function as oracle/ti_oracle.c:ti_normal (build-defined, include/ti_hip.h TI_SCHEME_EM)
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float ti_normal(uint64_t seed, long long traj, int step, int comp)
+{
+    uint32_t c[4] = {(uint32_t)traj, (uint32_t)((uint64_t)traj >> 32), (uint32_t)step, (uint32_t)(comp >> 2)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int pair = (comp & 3) >> 1;
+    const float u1 = ((float)(c[2 * pair] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2 * pair + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1)), a = 6.283185307179586f * u2;
+    return (comp & 1) ? r * sinf(a) : r * cosf(a);
+}
+
+// one thread per trajectory: x[traj][c] += sigma * (xi_c - COM_c)
+__global__ void noise_kernel(float* __restrict__ x, float sigma, uint64_t seed, long long traj0, int step, long long B, int comps,
+                             int atoms_for_com)
+{
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= B) return;
+    float com[3] = {0.f, 0.f, 0.f};
+    if (atoms_for_com > 0) {
+        for (int c = 0; c < comps; ++c) com[c % 3] += ti_normal(seed, traj0 + m, step, c);
+        for (int k = 0; k < 3; ++k) com[k] = com[k] / (float)atoms_for_com;
+    }
+    for (int c = 0; c < comps; ++c) {
+        float z = ti_normal(seed, traj0 + m, step, c);
+        if (atoms_for_com > 0) z -= com[c % 3];
+        x[m * comps + c] = __fadd_rn(x[m * comps + c], __fmul_rn(sigma, z));
+    }
+}
+
+__global__ void nan_check_kernel(const float* __restrict__ x, long long n, int* flag)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !isfinite(x[i])) *flag = 1;
+}
+
+// MFMA lane-map self-test: D = A * B with A[i][k] = 1 + i + 100k, B[k][j] = 1000 + j - 7k; also returns the
+// accumulator-layout ids so the host can check (reg, lane) -> (row, col) independently.
+__global__ void selftest_kernel(float* out)
+{
+    const int l = threadIdx.x;
+    const float a = 1.0f + (float)(l & 31) + 100.0f * (float)(l >> 5);
+    const float b = 1000.0f + (float)(l & 31) - 7.0f * (float)(l >> 5);
+    f32x16 acc = {0};
+    acc = mfma32(a, b, acc);
+    for (int i = 0; i < 16; ++i) out[l * 16 + i] = acc[i];
+}
+
+static inline dim3 grid1(long long n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+hipError_t launch_axpy(float* y, const float* x, float a, const float* b, long long n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(axpy_kernel, grid1(n, 256), dim3(256), 0, st, y, x, a, b, n);
+    return hipGetLastError();
+}
+hipError_t launch_heun(float* x, float hdt, const float* b1, const float* b2, long long n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(heun_kernel, grid1(n, 256), dim3(256), 0, st, x, hdt, b1, b2, n);
+    return hipGetLastError();
+}
+hipError_t launch_noise(float* x, float sigma, uint64_t seed, long long traj0, int step, long long B, int comps, int atoms_for_com,
+                        hipStream_t st)
+{
+    if (B > 0) hipLaunchKernelGGL(noise_kernel, grid1(B, 128), dim3(128), 0, st, x, sigma, seed, traj0, step, B, comps, atoms_for_com);
+    return hipGetLastError();
+}
+hipError_t launch_selftest(float* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, out);
+    return hipGetLastError();
+}
+hipError_t launch_nan_check(const float* x, long long n, int* flag, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(nan_check_kernel, grid1(n, 256), dim3(256), 0, st, x, n, flag);
+    return hipGetLastError();
+}
+
+}  // namespace ti

@@ -1,0 +1,243 @@
+// mfma_chain.hpp -- gfx950 building blocks shared by the drift kernels.
+//
+// Design: every dense layer of the drift networks is evaluated with the exact-f32 matrix
+// instruction v_mfma_f32_32x32x2_f32.  A wave owns 32 "rows" (edges, atoms or particles) and keeps their
+// activations in registers for the whole MLP chain:
+//
+//   * An activation set Act<NB> holds F = 32*NB features of 32 rows in NB*16 VGPRs per lane.  Lane l = (j, h) with
+//     j = l & 31 (the row) and h = l >> 5; register (nb, i) holds feature  feat(nb,i,h) = 32*nb + 8*(i>>2) + 4*h + (i&3).
+//     This is exactly the C/D accumulator layout of the 32x32 MFMA when the product is computed transposed,
+//     D[n][row] = sum_k W[n][k] * X[row][k]  (weights as the A operand, activations as the B operand), so the output
+//     of one layer is the B operand of the next with no data movement: k-step s uses register s of the input set.
+//   * Because 4 consecutive registers hold 4 consecutive features, a lane loads/stores rows of row-major [row][F]
+//     tensors and per-feature vectors (bias, gamma, beta) as float4 at offset 32*nb + 8*g + 4*h  (g = i>>2).
+//   * Weights are pre-packed on the host (pack.cpp) into "chunks": 32 output features x F inputs, laid out
+//     [k-step/4][lane][4] so that a wave reads one conflict-free ds_read_b128 per 4 MFMAs.  All waves of a workgroup
+//     walk the same chunk stream, double-buffered through LDS (one barrier per chunk).
+//   * The same chunk used with the operands swapped gives the flipped product D[row][n] (features on lanes, rows in
+//     registers), used where a reduction over rows is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ti {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+struct Act {
+    f32x16 b[NB];
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// row of the 32x32 accumulator held in register i of lane-half h
+__device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// ------------------------------------------------------------------------------------------------ weight chunk pipe
+// CH4 = float4 per chunk = 256*NB (KS = 16*NB k-steps x 64 lanes).  T = threads per workgroup.
+template <int NB, int T>
+struct Pipe {
+    static constexpr int CH4 = 256 * NB;
+    static constexpr int PER = (CH4 + T - 1) / T;
+    const f32x4* __restrict__ g;
+    f32x4* l[2];
+    int nch, idx, par;
+    f32x4 st[PER];
+
+    __device__ __forceinline__ void init(const f32x4* stream, int n_chunks, f32x4* lds)
+    {
+        g = stream; nch = n_chunks; idx = 0; par = 0;
+        l[0] = lds; l[1] = lds + CH4;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int o = threadIdx.x + k * T;
+            if (CH4 % T == 0 || o < CH4) l[0][o] = g[o];
+        }
+        __syncthreads();
+    }
+    // start of a chunk: kick off the global load of the following chunk, return the LDS image of the current one
+    __device__ __forceinline__ const f32x4* begin()
+    {
+        const int next = (idx + 1 == nch) ? 0 : idx + 1;
+        const f32x4* src = g + (size_t)next * CH4;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int o = threadIdx.x + k * T;
+            if (CH4 % T == 0 || o < CH4) st[k] = src[o];
+        }
+        return l[par];
+    }
+    __device__ __forceinline__ void end()
+    {
+        f32x4* dst = l[par ^ 1];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int o = threadIdx.x + k * T;
+            if (CH4 % T == 0 || o < CH4) dst[o] = st[k];
+        }
+        __syncthreads();
+        idx = (idx + 1 == nch) ? 0 : idx + 1;
+        par ^= 1;
+    }
+};
+
+// acc[n][row] += sum_k W[n][k] * in[row][k]      (transposed product; acc is one 32-feature output block)
+template <int NB>
+__device__ __forceinline__ void gemm_bt(f32x16& acc, const Act<NB>& in, const f32x4* wl, int lane)
+{
+#pragma unroll
+    for (int nbi = 0; nbi < NB; ++nbi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = wl[(nbi * 4 + g) * 64 + lane];
+            acc = mfma32(w.x, in.b[nbi][4 * g + 0], acc);
+            acc = mfma32(w.y, in.b[nbi][4 * g + 1], acc);
+            acc = mfma32(w.z, in.b[nbi][4 * g + 2], acc);
+            acc = mfma32(w.w, in.b[nbi][4 * g + 3], acc);
+        }
+}
+
+// acc[row][n] += sum_k in[row][k] * W[n][k]      (flipped: features n on lanes, rows in registers)
+template <int NB>
+__device__ __forceinline__ void gemm_fl(f32x16& acc, const Act<NB>& in, const f32x4* wl, int lane)
+{
+#pragma unroll
+    for (int nbi = 0; nbi < NB; ++nbi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = wl[(nbi * 4 + g) * 64 + lane];
+            acc = mfma32(in.b[nbi][4 * g + 0], w.x, acc);
+            acc = mfma32(in.b[nbi][4 * g + 1], w.y, acc);
+            acc = mfma32(in.b[nbi][4 * g + 2], w.z, acc);
+            acc = mfma32(in.b[nbi][4 * g + 3], w.w, acc);
+        }
+}
+
+// two independent flipped products sharing the k loop (phi and w output chunks): keeps two MFMA chains in flight
+template <int NB>
+__device__ __forceinline__ void gemm_fl2(f32x16& acc0, const Act<NB>& in0, const f32x4* wl0, f32x16& acc1, const Act<NB>& in1,
+                                         const f32x4* wl1, int lane)
+{
+#pragma unroll
+    for (int nbi = 0; nbi < NB; ++nbi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w0 = wl0[(nbi * 4 + g) * 64 + lane];
+            const f32x4 w1 = wl1[(nbi * 4 + g) * 64 + lane];
+            acc0 = mfma32(in0.b[nbi][4 * g + 0], w0.x, acc0);
+            acc1 = mfma32(in1.b[nbi][4 * g + 0], w1.x, acc1);
+            acc0 = mfma32(in0.b[nbi][4 * g + 1], w0.y, acc0);
+            acc1 = mfma32(in1.b[nbi][4 * g + 1], w1.y, acc1);
+            acc0 = mfma32(in0.b[nbi][4 * g + 2], w0.z, acc0);
+            acc1 = mfma32(in1.b[nbi][4 * g + 2], w1.z, acc1);
+            acc0 = mfma32(in0.b[nbi][4 * g + 3], w0.w, acc0);
+            acc1 = mfma32(in1.b[nbi][4 * g + 3], w1.w, acc1);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ row <-> set moves
+// one 32-feature block of a row-major row / per-feature vector: p points at feature 0
+__device__ __forceinline__ f32x16 load_block(const float* __restrict__ p, int nb, int h)
+{
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + 32 * nb + 8 * g + 4 * h);
+        r[4 * g + 0] = t.x; r[4 * g + 1] = t.y; r[4 * g + 2] = t.z; r[4 * g + 3] = t.w;
+    }
+    return r;
+}
+__device__ __forceinline__ void store_block(float* __restrict__ p, int nb, int h, const f32x16& r)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 t = {r[4 * g + 0], r[4 * g + 1], r[4 * g + 2], r[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(p + 32 * nb + 8 * g + 4 * h) = t;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void load_set(Act<NB>& a, const float* __restrict__ p, int h)
+{
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) a.b[nb] = load_block(p, nb, h);
+}
+template <int NB>
+__device__ __forceinline__ void store_set(float* __restrict__ p, int h, const Act<NB>& a)
+{
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) store_block(p, nb, h, a.b[nb]);
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise pieces
+// x * sigmoid(x); v_exp_f32 / v_rcp_f32 are ~1 ulp, far below the 1e-5 parity bar
+__device__ __forceinline__ float silu(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
+
+// torch.nn.LayerNorm(F, eps=1e-5) + SiLU over the features of each row, in place; `a` already holds x W^T + b.
+template <int NB>
+__device__ __forceinline__ void ln_silu(Act<NB>& a, const float* __restrict__ gamma, const float* __restrict__ beta, int h)
+{
+    constexpr float invF = 1.0f / (32.0f * NB);
+    float sum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += a.b[nb][i];
+    sum += xhalf(sum);
+    const float mean = sum * invF;
+    float var = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = a.b[nb][i] - mean;
+            var = fmaf(d, d, var);
+        }
+    var += xhalf(var);
+    const float rstd = 1.0f / sqrtf(var * invF + 1e-5f);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const f32x16 gm = load_block(gamma, nb, h);
+        const f32x16 bt = load_block(beta, nb, h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a.b[nb][i] = silu(fmaf((a.b[nb][i] - mean) * rstd, gm[i], bt[i]));
+    }
+}
+
+// PositionalEncoder (/root/reference/mdqm9/thermo/ambient/models/embedding.py:127-160) of one scalar per row, written
+// straight into the register layout: features 4m..4m+3 = cos(a(2m+1)), sin(a(2m+1)), cos(a(2m+2)), sin(a(2m+2)) with
+// a(k) = ((x / max_length) * k) * pi evaluated left to right in fp32 like the reference.
+template <int NB>
+__device__ __forceinline__ void posenc_set(Act<NB>& a, float x_over_len, int h)
+{
+    constexpr float PI_F = 3.14159265358979323846f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m = 8 * nb + 2 * g + h;
+            float s1, c1, s2, c2;
+            sincosf((x_over_len * (float)(2 * m + 1)) * PI_F, &s1, &c1);
+            sincosf((x_over_len * (float)(2 * m + 2)) * PI_F, &s2, &c2);
+            a.b[nb][4 * g + 0] = c1; a.b[nb][4 * g + 1] = s1; a.b[nb][4 * g + 2] = c2; a.b[nb][4 * g + 3] = s2;
+        }
+}
+
+// dot of a register set with a natural-order vector, summed over all F features of the row
+template <int NB>
+__device__ __forceinline__ float dot_set(const Act<NB>& a, const float* __restrict__ vec, int h)
+{
+    float acc = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const f32x16 w = load_block(vec, nb, h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = fmaf(a.b[nb][i], w[i], acc);
+    }
+    return acc + xhalf(acc);
+}
+
+}  // namespace ti

@@ -1,0 +1,725 @@
+// ti_api.hip -- host side of libti_hip.so: C ABI (include/ti_hip.h), weight packing, edge templates, HBM workspace,
+// drift / rollout orchestration on one HIP stream, live kernel timing with HIP events.
+//
+// There is deliberately no CPU fallback in this file: every entry point either runs the HIP kernels or fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <utility>
+
+#include "ti_internal.hpp"
+
+namespace ti {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIP_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
+    throw HipError(std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+
+// ---------------------------------------------------------------------------------------------------- packing
+void pack_chunk(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBin)
+{
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)NBin * 16 * 64);
+    for (int nbi = 0; nbi < NBin; ++nbi)
+        for (int g = 0; g < 4; ++g)
+            for (int l = 0; l < 64; ++l)
+                for (int q = 0; q < 4; ++q) {
+                    const int row = row0 + (l & 31), col = col0 + 32 * nbi + 8 * g + 4 * (l >> 5) + q;
+                    dst[base + ((size_t)(nbi * 4 + g) * 64 + l) * 4 + q] = row < n_rows ? W[(size_t)row * ld + col] : 0.f;
+                }
+}
+
+struct MlpOff { size_t W0, b0, g0, be0, W1, b1, g1, be1, W2, b2; int f_in, f_h, f_out; };
+static size_t take_mlp(MlpOff& m, size_t o, int f_in, int f_h, int f_out)
+{
+    m.f_in = f_in; m.f_h = f_h; m.f_out = f_out;
+    m.W0 = o; o += (size_t)f_h * f_in; m.b0 = o; o += f_h; m.g0 = o; o += f_h; m.be0 = o; o += f_h;
+    m.W1 = o; o += (size_t)f_h * f_h;  m.b1 = o; o += f_h; m.g1 = o; o += f_h; m.be1 = o; o += f_h;
+    m.W2 = o; o += (size_t)f_out * f_h; m.b2 = o; o += f_out;
+    return o;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    void alloc(size_t count) { release(); if (count) { HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T))); n = count; } }
+    void upload(const std::vector<T>& h) { alloc(h.size()); if (n) HIP_CHECK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice)); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { release(); }
+};
+
+struct Stream { size_t off4; int nch; };      // offset into the packed buffer in float4 units
+
+}  // namespace ti
+
+using namespace ti;
+
+// ====================================================================================================== handle
+struct ti_handle {
+    int kind = 0;                 // 0 painn, 1 adw
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[TI_KERNEL_COUNT];
+    // common device buffers
+    DevBuf<float> flat, packed;
+    DevBuf<int> nanflag;
+    long long cap = 0;            // trajectories the workspace is sized for
+
+    // ---- painn
+    ti_painn_desc d{};
+    int NB = 0, nE = 0, ncond = 0, G = 1, nblk = 0;
+    MlpOff embed{}, readout{}; std::vector<MlpOff> phi, w, upd; std::vector<size_t> U, V;
+    size_t edge_emb = 0, atom_emb = 0, Vr = 0; float b2_gate = 0.f;
+    Stream st_embed{}, st_readout{}; std::vector<Stream> st_edge, st_update;
+    DevBuf<uint32_t> rows; DevBuf<int32_t> slotnode, nslots, atom_ids;
+    std::vector<int> perm;        // sorted row -> original edge index
+    DevBuf<float> x, cond, s, P, v, dvacc, cacc, e, b1, b2, xt;
+    int tap = -1; long long last_B = 0;
+
+    // ---- adw
+    ti_adw_desc ad{};
+    size_t a_be_w_in = 0, a_be_b_in = 0, a_be_b_h = 0, a_be_w_out = 0, a_w_in = 0, a_b_in = 0, a_b_h = 0, a_w_out = 0;
+    float a_be_b_out = 0.f, a_b_out = 0.f;
+    Stream st_be{}, st_net{};
+    DevBuf<float> ax, ab1, ab2, axt, aemb_u, abeta0_u, abeta1_u; DevBuf<int32_t> aidx;
+    long long U_cap = 0;
+
+    ~ti_handle()
+    {
+        for (auto& v2 : ev) for (auto& pr : v2) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+    const float* F(size_t off) const { return flat.p + off; }
+    const float4* S(const Stream& s2) const { return reinterpret_cast<const float4*>(packed.p) + s2.off4; }
+    MlpVec vec(const MlpOff& m) const { return MlpVec{F(m.b0), F(m.g0), F(m.be0), F(m.b1), F(m.g1), F(m.be1), F(m.b2)}; }
+};
+
+namespace {
+
+struct Timed {           // RAII: brackets a launch with HIP events when profiling is on
+    ti_handle* h; int slot; hipEvent_t a = nullptr, b = nullptr;
+    Timed(ti_handle* h_, int slot_) : h(h_), slot(slot_)
+    {
+        if (!h->prof) return;
+        HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, h->stream));
+    }
+    ~Timed()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, h->stream);
+        h->ev[slot].emplace_back(a, b);
+    }
+};
+
+void set_device(const ti_handle* h) { HIP_CHECK(hipSetDevice(h->device)); }
+
+// ------------------------------------------------------------------------------------------------ painn create
+void build_template(ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype)
+{
+    const int A = h->d.n_atoms, E = h->d.n_edges;
+    h->perm.resize(E);
+    for (int k = 0; k < E; ++k) h->perm[k] = k;
+    std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) {
+        return dst[a] != dst[b] ? dst[a] < dst[b] : src[a] < src[b];
+    });
+    // group size: smallest G in 1..8 whose padding waste is <= 2 %, else the least wasteful
+    int bestG = 1; double bestW = 2.0;
+    for (int G = 1; G <= 8 && E > 0; ++G) {
+        const int rows = G * E, padded = (rows + 31) / 32 * 32;
+        const double waste = double(padded - rows) / padded;
+        if (waste < bestW - 1e-12) { bestW = waste; bestG = G; }
+        if (waste <= 0.02) { bestG = G; break; }
+    }
+    h->G = bestG;
+    const int rows = h->G * E;
+    h->nblk = (rows + 31) / 32;
+    std::vector<uint32_t> rw((size_t)h->nblk * 32, (uint32_t)63 << 18);
+    std::vector<int32_t> sn((size_t)h->nblk * 32, -1), ns(std::max(h->nblk, 1), 0);
+    for (int blk = 0; blk < h->nblk; ++blk) {
+        int nslot = 0, last_key = -1;
+        for (int j = 0; j < 32; ++j) {
+            const int r = blk * 32 + j;
+            if (r >= rows) break;
+            const int m = r / E, k = h->perm[r % E];
+            const int key = m * 256 + dst[k];
+            if (key != last_key) { sn[(size_t)blk * 32 + nslot] = (m << 8) | dst[k]; ++nslot; last_key = key; }
+            rw[r] = 1u | ((uint32_t)m << 1) | ((uint32_t)src[k] << 6) | ((uint32_t)dst[k] << 11) | ((uint32_t)etype[k] << 16) |
+                    ((uint32_t)(nslot - 1) << 18);
+        }
+        ns[blk] = nslot;
+    }
+    (void)A;
+    h->rows.upload(rw); h->slotnode.upload(sn); h->nslots.upload(ns);
+}
+
+void pack_painn(ti_handle* h, const float* wts)
+{
+    const int F = h->d.n_features, L = h->d.n_layers, NB = h->NB, nE = h->nE;
+    std::vector<float> pk;
+    auto begin_stream = [&]() { return pk.size() / 4; };
+    auto end_stream = [&](size_t off4) { return Stream{off4, (int)((pk.size() / 4 - off4) / (256 * (size_t)NB))}; };
+    auto layer = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) pack_chunk(pk, wts + W, ld, n_rows, 32 * nbo, col0, NB); };
+    // embed: L1 by input segment, L2, L3, then P for the first message block
+    size_t o = begin_stream();
+    for (int seg = 0; seg < nE; ++seg) layer(h->embed.W0, nE * F, F, seg * F);
+    layer(h->embed.W1, F, F, 0); layer(h->embed.W2, F, F, 0);
+    if (L > 0) layer(h->phi[0].W0, 2 * F, F, 0);
+    else for (int nbo = 0; nbo < NB; ++nbo) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f);
+    h->st_embed = end_stream(o);
+    for (int l = 0; l < L; ++l) {
+        const bool first = l == 0, last = l == L - 1;
+        o = begin_stream();
+        layer(h->w[l].W0, F, F, 0); layer(h->w[l].W1, F, F, 0);
+        layer(h->phi[l].W0, 2 * F, F, F);          // the e half of [s[src] | e]
+        layer(h->phi[l].W1, F, F, 0);
+        for (int nbo = 0; nbo < NB; ++nbo)
+            for (int c : {2, 3, 1, 0, 4}) {       // consumption order of painn_edge_kernel: ds, de, sed, gates, cross gates
+                if (c == 3 && last) continue;
+                if ((c == 0 || c == 4) && first) continue;
+                pack_chunk(pk, wts + h->phi[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NB);
+                pack_chunk(pk, wts + h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NB);
+            }
+        h->st_edge.push_back(end_stream(o));
+        o = begin_stream();
+        for (int c = 0; c < 3; ++c) layer(h->V[l], F, F, 0);
+        layer(h->upd[l].W0, 2 * F, F, 0); layer(h->upd[l].W0, 2 * F, F, F);
+        layer(h->upd[l].W1, F, F, 0);
+        for (int nbo = 0; nbo < NB; ++nbo) {
+            pack_chunk(pk, wts + h->upd[l].W2, F, 3 * F, F + 32 * nbo, 0, NB);       // scale_squared_norm
+            pack_chunk(pk, wts + h->upd[l].W2, F, 3 * F, 2 * F + 32 * nbo, 0, NB);   // add_invariant_features
+        }
+        layer(h->upd[l].W2, F, 3 * F, 0);                                             // gates
+        for (int c = 0; c < 3; ++c) layer(h->U[l], F, F, 0);
+        if (!last) layer(h->phi[l + 1].W0, 2 * F, F, 0);
+        h->st_update.push_back(end_stream(o));
+    }
+    o = begin_stream();
+    layer(h->readout.W0, F, F, 0); layer(h->readout.W1, F, F, 0);
+    h->st_readout = end_stream(o);
+    h->packed.upload(pk);
+}
+
+void ensure_painn_ws(ti_handle* h, long long B)
+{
+    if (B <= h->cap) return;
+    const size_t A = h->d.n_atoms, F = h->d.n_features, N = (size_t)B * A;
+    const size_t groups = ((size_t)B + h->G - 1) / h->G;
+    h->x.alloc(N * 3); h->b1.alloc(N * 3); h->b2.alloc(N * 3); h->xt.alloc(N * 3);
+    h->cond.alloc(std::max<size_t>(N * h->ncond, 1));
+    h->s.alloc(N * F); h->P.alloc(N * F);
+    h->v.alloc(N * 3 * F); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F);
+    h->e.alloc(std::max<size_t>(groups * h->nblk * 32 * F, 1));
+    h->cap = B;
+}
+
+// one drift evaluation, everything on h->stream; x_dev / out_dev are device pointers [B*A*3]
+void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* cond_dev, long long B, float* out_dev)
+{
+    const int A = h->d.n_atoms, F = h->d.n_features, L = h->d.n_layers, NB = h->NB;
+    const long long N = B * A, groups = (B + h->G - 1) / h->G;
+    hipStream_t st = h->stream;
+    const size_t vbytes = (size_t)N * 3 * F * sizeof(float);
+    HIP_CHECK(hipMemsetAsync(h->v.p, 0, vbytes, st));
+    HIP_CHECK(hipMemsetAsync(h->dvacc.p, 0, vbytes, st));
+    HIP_CHECK(hipMemsetAsync(h->cacc.p, 0, vbytes, st));
+    {
+        EmbedParams p{};
+        p.stream = h->S(h->st_embed); p.nch = h->st_embed.nch; p.mlp = h->vec(h->embed);
+        p.pb0 = L > 0 ? h->F(h->phi[0].b0) : h->F(h->embed.b2);
+        p.atom_emb = h->F(h->atom_emb); p.atom_ids = h->atom_ids.p; p.cond = cond_dev; p.ncond = h->ncond; p.A = A; p.N = N;
+        p.t = t; p.temp_length = h->d.temp_length; p.time_length = h->d.time_length; p.temp_mean = h->d.temp_mean; p.temp_range = h->d.temp_range;
+        p.s = h->s.p; p.P = h->P.p;
+        Timed tm(h, TI_KERNEL_PAINN_EMBED);
+        HIP_CHECK(launch_embed(NB, h->nE, p, st));
+    }
+    h->last_B = B;
+    if (h->tap == 0) return;
+    for (int l = 0; l < L; ++l) {
+        if (h->nblk > 0) {
+            EdgeParams p{};
+            p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.phi = h->vec(h->phi[l]); p.w = h->vec(h->w[l]);
+            p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p; p.nslots = h->nslots.p;
+            p.nblk = h->nblk; p.G = h->G; p.A = A; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
+            p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.s = h->s.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
+            Timed tm(h, TI_KERNEL_PAINN_EDGE);
+            HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, p, st));
+        }
+        if (h->tap == 1 + 2 * l) return;
+        {
+            UpdateParams p{};
+            p.stream = h->S(h->st_update[l]); p.nch = h->st_update[l].nch; p.mlp = h->vec(h->upd[l]);
+            p.pb0_next = l + 1 < L ? h->F(h->phi[l + 1].b0) : nullptr;
+            p.N = N; p.s = h->s.p; p.v = h->v.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.P = h->P.p;
+            Timed tm(h, TI_KERNEL_PAINN_UPDATE);
+            HIP_CHECK(launch_update(NB, l + 1 < L, p, st));
+        }
+        if (h->tap == 2 + 2 * l) return;
+    }
+    {
+        ReadoutParams p{};
+        p.stream = h->S(h->st_readout); p.nch = h->st_readout.nch; p.mlp = h->vec(h->readout);
+        p.w2_gate = h->F(h->readout.W2 + F); p.b2_gate = h->b2_gate; p.Vr = h->F(h->Vr);
+        p.N = N; p.s = h->s.p; p.v = h->v.p; p.out = out_dev;
+        Timed tm(h, TI_KERNEL_PAINN_READOUT);
+        HIP_CHECK(launch_readout(NB, p, st));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ adw helpers
+void adw_mlp_launch(ti_handle* h, bool embed, const float* a0, const float* in1, const float* emb, const int32_t* idx, float t,
+                    long long rows, float* out)
+{
+    AdwParams p{};
+    const Stream& s2 = embed ? h->st_be : h->st_net;
+    p.stream = h->S(s2); p.nch = s2.nch;
+    p.w_in = h->F(embed ? h->a_be_w_in : h->a_w_in); p.b_in = h->F(embed ? h->a_be_b_in : h->a_b_in);
+    p.b_hidden = h->F(embed ? h->a_be_b_h : h->a_b_h); p.w_out = h->F(embed ? h->a_be_w_out : h->a_w_out);
+    p.b_out = embed ? h->a_be_b_out : h->a_b_out; p.n_hidden = embed ? 1 : h->ad.num_layers - 1; p.B = rows;
+    p.x = a0; p.in1 = in1; p.emb = emb; p.idx = idx; p.t = t; p.out = out;
+    Timed tm(h, TI_KERNEL_ADW);
+    HIP_CHECK(launch_adw(h->NB, p, h->stream));
+}
+
+// upload conditioning: dedupe (beta0, beta1) pairs on the host (the driver uses one pair, adw/sample.py:24)
+long long adw_set_cond(ti_handle* h, const float* beta0, const float* beta1, long long B, int mem)
+{
+    std::vector<float> b0(B), b1(B);
+    if (mem == TI_MEM_DEVICE) {
+        HIP_CHECK(hipMemcpy(b0.data(), beta0, B * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(b1.data(), beta1, B * sizeof(float), hipMemcpyDeviceToHost));
+    } else { std::memcpy(b0.data(), beta0, B * sizeof(float)); std::memcpy(b1.data(), beta1, B * sizeof(float)); }
+    std::map<std::pair<float, float>, int> uniq;
+    std::vector<int32_t> idx(B);
+    std::vector<float> u0, u1;
+    for (long long i = 0; i < B; ++i) {
+        auto key = std::make_pair(b0[i], b1[i]);
+        auto it = uniq.find(key);
+        if (it == uniq.end()) { it = uniq.emplace(key, (int)u0.size()).first; u0.push_back(b0[i]); u1.push_back(b1[i]); }
+        idx[i] = it->second;
+    }
+    h->aidx.upload(idx); h->abeta0_u.upload(u0); h->abeta1_u.upload(u1);
+    h->aemb_u.alloc(u0.size());
+    return (long long)u0.size();
+}
+
+void adw_drift_dev(ti_handle* h, const float* x_dev, float t, long long U, long long B, float* out_dev)
+{
+    adw_mlp_launch(h, true, h->abeta0_u.p, h->abeta1_u.p, nullptr, nullptr, t, U, h->aemb_u.p);     // beta_embed([b0, b1, t])
+    adw_mlp_launch(h, false, x_dev, nullptr, h->aemb_u.p, h->aidx.p, t, B, out_dev);               // net([x, t, embed])
+}
+
+void ensure_adw_ws(ti_handle* h, long long B)
+{
+    if (B <= h->cap) return;
+    h->ax.alloc(B); h->ab1.alloc(B); h->ab2.alloc(B); h->axt.alloc(B);
+    h->cap = B;
+}
+
+// ------------------------------------------------------------------------------------------------ shared rollout
+// drift(x_dev, t, out_dev) evaluates the drift; state arrays have n floats; comps = floats per trajectory
+template <typename Drift>
+int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1, float* b2, float* xt, size_t n, long long B, int comps,
+                   int atoms_for_com, float* out_path, int64_t* n_fevals, Drift&& drift)
+{
+    hipStream_t st = h->stream;
+    const hipMemcpyKind out_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    int64_t row = 0, fe = 0;
+    auto save = [&]() { HIP_CHECK(hipMemcpyAsync(out_path + (size_t)(row++) * n, x, n * sizeof(float), out_kind, st)); };
+    if (rd->save_every > 0) save();
+    for (int k = 0; k < rd->n_step - 1; ++k) {
+        const float dt = rd->t_grid[k + 1] - rd->t_grid[k];
+        drift(x, rd->t_grid[k], b1); ++fe;
+        if (rd->scheme == TI_SCHEME_HEUN) {
+            { Timed tm(h, TI_KERNEL_INTEGRATE); HIP_CHECK(launch_axpy(xt, x, dt, b1, (long long)n, st)); }
+            drift(xt, rd->t_grid[k + 1], b2); ++fe;
+            { Timed tm(h, TI_KERNEL_INTEGRATE); HIP_CHECK(launch_heun(x, 0.5f * dt, b1, b2, (long long)n, st)); }
+        } else {
+            Timed tm(h, TI_KERNEL_INTEGRATE);
+            HIP_CHECK(launch_axpy(x, x, dt, b1, (long long)n, st));
+            if (rd->scheme == TI_SCHEME_EM && rd->eps > 0.0f)
+                HIP_CHECK(launch_noise(x, std::sqrt(2.0f * rd->eps * std::fabs(dt)), rd->seed, rd->traj_offset, k, B, comps,
+                                       rd->com_free_noise ? atoms_for_com : 0, st));
+        }
+        const int step = k + 1;
+        if (rd->save_every > 0 && (step % rd->save_every == 0 || step == rd->n_step - 1)) save();
+    }
+    if (rd->save_every <= 0) save();
+    HIP_CHECK(hipMemsetAsync(h->nanflag.p, 0, sizeof(int), st));
+    HIP_CHECK(launch_nan_check(x, (long long)n, h->nanflag.p, st));
+    int flag = 0;
+    HIP_CHECK(hipMemcpyAsync(&flag, h->nanflag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (n_fevals) *n_fevals = fe;
+    return flag ? fail(TI_E_NAN, "non-finite value in the final state") : TI_OK;
+}
+
+int check_rollout_desc(const ti_rollout_desc* rd)
+{
+    if (!rd || !rd->t_grid) return fail(TI_E_ARG, "rollout desc / t_grid is NULL");
+    if (rd->n_step < 1) return fail(TI_E_ARG, "n_step must be >= 1");
+    if (rd->scheme < TI_SCHEME_EULER || rd->scheme > TI_SCHEME_EM) return fail(TI_E_ARG, "unknown scheme");
+    if (rd->mem != TI_MEM_HOST && rd->mem != TI_MEM_DEVICE) return fail(TI_E_ARG, "unknown mem kind");
+    if (rd->eps < 0.f) return fail(TI_E_ARG, "eps must be >= 0");
+    return TI_OK;
+}
+
+template <typename Fn>
+int guarded(Fn&& fn)
+{
+    try { return fn(); }
+    catch (const HipError& e) { return fail(TI_E_HIP, e.what()); }
+    catch (const std::bad_alloc&) { return fail(TI_E_ALLOC, "host allocation failed"); }
+    catch (const std::exception& e) { return fail(TI_E_ARG, e.what()); }
+}
+
+ti_handle* new_handle(int kind, int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw HipError("no HIP device available (libti_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<ti_handle> h(new ti_handle());
+    h->kind = kind; h->device = device;
+    HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    h->nanflag.alloc(1);
+    return h.release();
+}
+
+}  // namespace
+
+// ====================================================================================================== C ABI
+extern "C" {
+
+int ti_version(void) { return TI_ABI_VERSION; }
+
+int ti_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+const char* ti_last_error(void) { return g_err.c_str(); }
+
+int64_t ti_rollout_rows(int32_t n_step, int32_t save_every)
+{
+    if (save_every <= 0) return 1;
+    const int64_t steps = n_step - 1;
+    return steps / save_every + 1 + (steps % save_every != 0);
+}
+
+ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t n_weights, const int32_t* edge_src,
+                           const int32_t* edge_dst, const int32_t* edge_type, const int32_t* atom_ids, int device)
+{
+    ti_handle* out = nullptr;
+    const int rc = guarded([&]() -> int {
+        if (!d || !weights || !atom_ids) return fail(TI_E_ARG, "NULL argument");
+        const int F = d->n_features, L = d->n_layers, A = d->n_atoms, E = d->n_edges;
+        if (F != 32 && F != 64 && F != 128 && F != 256) return fail(TI_E_UNSUPPORTED, "n_features must be 32, 64, 128 or 256");
+        if (L < 1) return fail(TI_E_ARG, "n_layers must be >= 1");
+        if (A < 1 || A > 32) return fail(TI_E_UNSUPPORTED, "n_atoms must be in 1..32 (the reference caps it at n_types = 25)");
+        if (E < 0 || (E > 0 && (!edge_src || !edge_dst || !edge_type))) return fail(TI_E_ARG, "edge arrays missing");
+        if (d->variant < 0 || d->variant > 2) return fail(TI_E_ARG, "unknown variant");
+        if (d->n_types < 1) return fail(TI_E_ARG, "n_types must be >= 1");
+        for (int k = 0; k < E; ++k)
+            if (edge_src[k] < 0 || edge_src[k] >= A || edge_dst[k] < 0 || edge_dst[k] >= A || edge_type[k] < 0 || edge_type[k] > 3)
+                return fail(TI_E_ARG, "edge index / type out of range");
+        for (int a = 0; a < A; ++a) if (atom_ids[a] < 0 || atom_ids[a] >= d->n_types) return fail(TI_E_ARG, "atom id out of range");
+        std::unique_ptr<ti_handle> h(new_handle(0, device));
+        h->d = *d; h->NB = F / 32;
+        h->nE = d->variant == TI_VARIANT_AMBIENT ? 4 : d->variant == TI_VARIANT_LATENT_MULTI ? 3 : 2;
+        h->ncond = d->variant == TI_VARIANT_AMBIENT ? 2 : d->variant == TI_VARIANT_LATENT_MULTI ? 1 : 0;
+        // canonical layout offsets (include/ti_hip.h)
+        size_t o = 0;
+        h->edge_emb = o; o += 4 * (size_t)F; h->atom_emb = o; o += (size_t)d->n_types * F;
+        o = take_mlp(h->embed, o, h->nE * F, F, F);
+        h->phi.resize(L); h->w.resize(L); h->upd.resize(L); h->U.resize(L); h->V.resize(L);
+        for (int l = 0; l < L; ++l) {
+            o = take_mlp(h->phi[l], o, 2 * F, F, 5 * F); o = take_mlp(h->w[l], o, F, F, 5 * F);
+            h->U[l] = o; o += (size_t)F * F; h->V[l] = o; o += (size_t)F * F;
+            o = take_mlp(h->upd[l], o, 2 * F, F, 3 * F);
+        }
+        o = take_mlp(h->readout, o, F, F, 2);
+        h->Vr = o; o += F;
+        if (o != n_weights) return fail(TI_E_ARG, "weight count mismatch: expected " + std::to_string(o) + ", got " + std::to_string(n_weights));
+        h->b2_gate = weights[h->readout.b2 + 1];
+        // natural-order copy; Vr follows the 2-float readout bias in the canonical layout, so a 16-byte aligned copy of it
+        // is appended for the kernels' float4 loads
+        std::vector<float> flat(weights, weights + n_weights);
+        while (flat.size() % 4) flat.push_back(0.f);
+        const size_t vr_aligned = flat.size();
+        flat.insert(flat.end(), weights + h->Vr, weights + h->Vr + F);
+        h->Vr = vr_aligned;
+        h->flat.upload(flat);
+        h->atom_ids.upload(std::vector<int32_t>(atom_ids, atom_ids + A));
+        build_template(h.get(), edge_src, edge_dst, edge_type);
+        pack_painn(h.get(), weights);
+        HIP_CHECK(configure_painn_kernels(h->NB));
+        out = h.release();
+        return TI_OK;
+    });
+    return rc == TI_OK ? out : nullptr;
+}
+
+int ti_reserve(ti_handle* h, int64_t B)
+{
+    if (!h || B < 0) return fail(TI_E_ARG, "bad handle / B");
+    return guarded([&]() -> int { set_device(h); if (h->kind == 0) ensure_painn_ws(h, B); else ensure_adw_ws(h, B); return TI_OK; });
+}
+
+int ti_painn_drift(ti_handle* h, const float* x, float t, const float* cond, int64_t B, float* out, int mem)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (B < 0 || (B > 0 && (!x || !out || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
+    if (B == 0) return TI_OK;
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_painn_ws(h, B);
+        const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
+        const float *xd = x, *cd = cond; float* od = out;
+        if (mem == TI_MEM_HOST) {
+            HIP_CHECK(hipMemcpyAsync(h->x.p, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            if (nc) HIP_CHECK(hipMemcpyAsync(h->cond.p, cond, nc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            xd = h->x.p; cd = h->cond.p; od = h->b1.p;
+        }
+        painn_drift_dev(h, xd, t, cd, B, od);
+        if (mem == TI_MEM_HOST && h->tap < 0) HIP_CHECK(hipMemcpyAsync(out, od, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return TI_OK;
+    });
+}
+
+int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, const float* cond, int64_t B, float* out_path,
+                     int64_t* n_fevals)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (int rc = check_rollout_desc(rd)) return rc;
+    if (B < 0 || (B > 0 && (!x0 || !out_path || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
+    if (B == 0) { if (n_fevals) *n_fevals = 0; return TI_OK; }
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_painn_ws(h, B);
+        const int A = h->d.n_atoms;
+        const size_t n = (size_t)B * A * 3, nc = (size_t)B * A * h->ncond;
+        const hipMemcpyKind in_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIP_CHECK(hipMemcpyAsync(h->x.p, x0, n * sizeof(float), in_kind, h->stream));
+        const float* cd = cond;
+        if (rd->mem == TI_MEM_HOST && nc) { HIP_CHECK(hipMemcpyAsync(h->cond.p, cond, nc * sizeof(float), hipMemcpyHostToDevice, h->stream)); cd = h->cond.p; }
+        const int saved_tap = h->tap; h->tap = -1;
+        const int rc = rollout_common(h, rd, h->x.p, h->b1.p, h->b2.p, h->xt.p, n, B, A * 3, A, out_path, n_fevals,
+                                      [&](const float* xs, float t, float* o) { painn_drift_dev(h, xs, t, cd, B, o); });
+        h->tap = saved_tap;
+        return rc;
+    });
+}
+
+int ti_painn_debug_tap(ti_handle* h, int stage)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    h->tap = stage;
+    return TI_OK;
+}
+
+int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)
+{
+    if (!h || h->kind != 0 || !out) return fail(TI_E_ARG, "bad argument");
+    return guarded([&]() -> int {
+        set_device(h);
+        const size_t A = h->d.n_atoms, F = h->d.n_features, E = h->d.n_edges, B = (size_t)h->last_B, N = B * A;
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (what == 0) {
+            if (n_floats != N * F) return fail(TI_E_ARG, "size mismatch (s)");
+            HIP_CHECK(hipMemcpy(out, h->s.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+        } else if (what == 1) {
+            // v as the reference sees it at the tap: v + dvacc + cacc x v (the accumulators are zero after an update stage)
+            if (n_floats != N * 3 * F) return fail(TI_E_ARG, "size mismatch (v)");
+            std::vector<float> v(n_floats), dv(n_floats), cc(n_floats);
+            HIP_CHECK(hipMemcpy(v.data(), h->v.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(dv.data(), h->dvacc.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(cc.data(), h->cacc.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t nd = 0; nd < N; ++nd)
+                for (size_t f = 0; f < F; ++f)
+                    for (int c = 0; c < 3; ++c) {
+                        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                        auto at = [&](const std::vector<float>& a, int cc2) { return a[(nd * 3 + cc2) * F + f]; };
+                        out[(nd * 3 + c) * F + f] = (at(v, c) + at(dv, c)) + (at(cc, c1) * at(v, c2) - at(cc, c2) * at(v, c1));
+                    }
+        } else if (what == 2) {
+            if (n_floats != B * E * F) return fail(TI_E_ARG, "size mismatch (e)");
+            const size_t groups = (B + h->G - 1) / h->G, rows = groups * h->nblk * 32;
+            std::vector<float> e(rows * F);
+            HIP_CHECK(hipMemcpy(e.data(), h->e.p, e.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t m = 0; m < B; ++m)
+                for (size_t k = 0; k < E; ++k) {
+                    const size_t gi = m / h->G, r = (m % h->G) * E + k;          // k = sorted position
+                    std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + (gi * h->nblk * 32 + r) * F, F * sizeof(float));
+                }
+        } else return fail(TI_E_ARG, "unknown tap");
+        return TI_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------ adw
+ti_handle* ti_adw_create(const ti_adw_desc* d, const double* weights, size_t n_weights, int device)
+{
+    ti_handle* out = nullptr;
+    const int rc = guarded([&]() -> int {
+        if (!d || !weights) return fail(TI_E_ARG, "NULL argument");
+        const int H = d->hidden_size, nl = d->num_layers;
+        if (H != 32 && H != 64 && H != 128 && H != 256) return fail(TI_E_UNSUPPORTED, "hidden_size must be 32, 64, 128 or 256");
+        if (nl < 1) return fail(TI_E_ARG, "num_layers must be >= 1");
+        const size_t need = (size_t)H * 3 + H + (size_t)H * H + H + H + 1 + (size_t)H * 3 + H + (size_t)(nl - 1) * ((size_t)H * H + H) + H + 1;
+        if (n_weights != need) return fail(TI_E_ARG, "weight count mismatch: expected " + std::to_string(need) + ", got " + std::to_string(n_weights));
+        std::unique_ptr<ti_handle> h(new_handle(1, device));
+        h->ad = *d; h->NB = H / 32;
+        std::vector<float> w(n_weights);
+        for (size_t i = 0; i < n_weights; ++i) w[i] = (float)weights[i];        // the device computes in fp32
+        // natural-order vectors are repacked so every vector the kernel float4-loads is 16-byte aligned
+        std::vector<float> nat, pk;
+        auto push = [&](const float* p, size_t n) { size_t off = nat.size(); nat.insert(nat.end(), p, p + n); while (nat.size() % 4) nat.push_back(0.f); return off; };
+        size_t o = 0;
+        h->a_be_w_in = push(&w[o], (size_t)H * 3); o += (size_t)H * 3;
+        h->a_be_b_in = push(&w[o], H); o += H;
+        const size_t be_W1 = o; o += (size_t)H * H;
+        h->a_be_b_h = push(&w[o], H); o += H;
+        h->a_be_w_out = push(&w[o], H); o += H;
+        h->a_be_b_out = w[o]; o += 1;
+        h->a_w_in = push(&w[o], (size_t)H * 3); o += (size_t)H * 3;
+        h->a_b_in = push(&w[o], H); o += H;
+        std::vector<size_t> Wh; std::vector<float> bh;
+        for (int l = 1; l < nl; ++l) { Wh.push_back(o); o += (size_t)H * H; bh.insert(bh.end(), &w[o], &w[o] + H); o += H; }
+        if (bh.empty()) bh.assign(4, 0.f);
+        h->a_b_h = push(bh.data(), bh.size());
+        h->a_w_out = push(&w[o], H); o += H;
+        h->a_b_out = w[o]; o += 1;
+        const int NB = h->NB;
+        h->st_be.off4 = 0;
+        for (int nbo = 0; nbo < NB; ++nbo) pack_chunk(pk, &w[be_W1], H, H, 32 * nbo, 0, NB);
+        h->st_be.nch = NB;
+        h->st_net.off4 = pk.size() / 4;
+        for (size_t Wl : Wh) for (int nbo = 0; nbo < NB; ++nbo) pack_chunk(pk, &w[Wl], H, H, 32 * nbo, 0, NB);
+        h->st_net.nch = (int)Wh.size() * NB;
+        if (pk.empty()) pk.assign(4, 0.f);
+        h->flat.upload(nat); h->packed.upload(pk);
+        HIP_CHECK(configure_adw_kernels(NB));
+        out = h.release();
+        return TI_OK;
+    });
+    return rc == TI_OK ? out : nullptr;
+}
+
+int ti_adw_drift(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out, int mem)
+{
+    if (!h || h->kind != 1) return fail(TI_E_ARG, "not an adw handle");
+    if (B < 0 || (B > 0 && (!x || !beta0 || !beta1 || !out))) return fail(TI_E_ARG, "NULL buffer");
+    if (B == 0) return TI_OK;
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_adw_ws(h, B);
+        const long long U = adw_set_cond(h, beta0, beta1, B, mem);
+        const float* xd = x; float* od = out;
+        if (mem == TI_MEM_HOST) { HIP_CHECK(hipMemcpyAsync(h->ax.p, x, B * sizeof(float), hipMemcpyHostToDevice, h->stream)); xd = h->ax.p; od = h->ab1.p; }
+        adw_drift_dev(h, xd, t, U, B, od);
+        if (mem == TI_MEM_HOST) HIP_CHECK(hipMemcpyAsync(out, od, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return TI_OK;
+    });
+}
+
+int ti_adw_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, const float* beta0, const float* beta1, int64_t B,
+                   float* out_path, int64_t* n_fevals)
+{
+    if (!h || h->kind != 1) return fail(TI_E_ARG, "not an adw handle");
+    if (int rc = check_rollout_desc(rd)) return rc;
+    if (B < 0 || (B > 0 && (!x0 || !beta0 || !beta1 || !out_path))) return fail(TI_E_ARG, "NULL buffer");
+    if (B == 0) { if (n_fevals) *n_fevals = 0; return TI_OK; }
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_adw_ws(h, B);
+        const long long U = adw_set_cond(h, beta0, beta1, B, rd->mem);
+        const hipMemcpyKind in_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIP_CHECK(hipMemcpyAsync(h->ax.p, x0, B * sizeof(float), in_kind, h->stream));
+        return rollout_common(h, rd, h->ax.p, h->ab1.p, h->ab2.p, h->axt.p, (size_t)B, B, 1, 0, out_path, n_fevals,
+                              [&](const float* xs, float t, float* o) { adw_drift_dev(h, xs, t, U, B, o); });
+    });
+}
+
+// --------------------------------------------------------------------------------------------------------- shared
+void ti_destroy(ti_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+int ti_set_stream(ti_handle* h, void* hip_stream)
+{
+    if (!h) return fail(TI_E_ARG, "NULL handle");
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return TI_OK;
+}
+
+int ti_profile_enable(ti_handle* h, int on)
+{
+    if (!h) return fail(TI_E_ARG, "NULL handle");
+    h->prof = on != 0;
+    return TI_OK;
+}
+
+int ti_profile_read(ti_handle* h, int kernel, int64_t* n_launches, double* total_ms)
+{
+    if (!h || kernel < 0 || kernel >= TI_KERNEL_COUNT) return fail(TI_E_ARG, "bad handle / kernel id");
+    return guarded([&]() -> int {
+        set_device(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        double tot = 0; int64_t cnt = 0;
+        for (auto& pr : h->ev[kernel]) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            tot += ms; ++cnt;
+            (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+        }
+        h->ev[kernel].clear();
+        if (n_launches) *n_launches = cnt;
+        if (total_ms) *total_ms = tot;
+        return TI_OK;
+    });
+}
+
+int ti_selftest(int device)
+{
+    return guarded([&]() -> int {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TI_E_HIP, "no HIP device");
+        HIP_CHECK(hipSetDevice(device));
+        DevBuf<float> d; d.alloc(64 * 16);
+        HIP_CHECK(launch_selftest(d.p, nullptr));
+        std::vector<float> o(64 * 16);
+        HIP_CHECK(hipMemcpy(o.data(), d.p, o.size() * sizeof(float), hipMemcpyDeviceToHost));
+        // expected D[i][j] = sum_k A[i][k] B[k][j], A[i][k] = 1 + i + 100k, B[k][j] = 1000 + j - 7k;
+        // accumulator register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+                double ref = 0;
+                for (int k = 0; k < 2; ++k) ref += (1.0 + i + 100.0 * k) * (1000.0 + j - 7.0 * k);
+                if (std::fabs(o[l * 16 + r] - ref) > 1e-3 * std::fabs(ref))
+                    return fail(TI_E_HIP, "MFMA 32x32x2 lane map differs from the layout the kernels assume (lane " + std::to_string(l) +
+                                              ", reg " + std::to_string(r) + ")");
+            }
+        return TI_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// ti_internal.hpp -- host/device shared declarations of libti_hip.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ti_hip.h"
+
+namespace ti {
+
+// ---- molecule-group edge template -------------------------------------------------------------------------------
+// The E_m edges of one molecule are sorted by (dst, src); G molecules form a "group" whose G*E_m edge rows are padded
+// to NBLK blocks of 32 rows.  One wave owns one group, so every per-atom sum over incoming edges stays inside a wave
+// (deterministic, no atomics).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots".
+//   row word : bit0 valid | mol_local<<1 (5b) | src<<6 (5b) | dst<<11 (5b) | etype<<16 (2b) | slot<<18 (6b, 63 = none)
+//   slot word: mol_local<<8 | atom     (-1 = unused)
+constexpr int ROW_VALID = 1;
+__host__ __device__ inline int row_mol(uint32_t w) { return (w >> 1) & 31; }
+__host__ __device__ inline int row_src(uint32_t w) { return (w >> 6) & 31; }
+__host__ __device__ inline int row_dst(uint32_t w) { return (w >> 11) & 31; }
+__host__ __device__ inline int row_type(uint32_t w) { return (w >> 16) & 3; }
+__host__ __device__ inline int row_slot(uint32_t w) { return (w >> 18) & 63; }
+
+struct MlpVec {           // natural-order per-feature vectors of one reference MLP block (device pointers)
+    const float *b0, *g0, *be0, *b1, *g1, *be1, *b2;
+};
+
+struct EdgeParams {
+    const float4* stream; int nch;         // packed weight chunks of this layer's message block
+    MlpVec phi, w;                          // phi.b0 is folded into P by the node kernels
+    const float* edge_emb;                  // [4][F]  (first layer: e = edge_emb[type])
+    const uint32_t* rows; const int32_t* slotnode; const int32_t* nslots;
+    int nblk, G, A;
+    long long B, n_groups;
+    float length_scale;
+    const float* x;                         // [B*A][3]
+    const float* P;                         // [B*A][F]   s @ W0[:, :F]^T + b0
+    const float* v;                         // [B*A][3][F]
+    float* s;                               // [B*A][F]   += sum ds
+    float* dvacc;                           // [B*A][3][F] += sum (sed*dir + gates*v[src])
+    float* cacc;                            // [B*A][3][F] += sum cg*dir   (crossed with v[dst] in the update kernel)
+    float* e;                               // [n_groups*nblk*32][F]
+};
+
+struct EmbedParams {
+    const float4* stream; int nch;
+    MlpVec mlp; const float* pb0;           // pb0 = phi[0].b0
+    const float* atom_emb; const int32_t* atom_ids; const float* cond;
+    int ncond, A; long long N;
+    float t, temp_length, time_length, temp_mean, temp_range;
+    float* s; float* P;
+};
+
+struct UpdateParams {
+    const float4* stream; int nch;
+    MlpVec mlp; const float* pb0_next;
+    long long N;
+    float *s, *v, *dvacc, *cacc, *P;
+};
+
+struct ReadoutParams {
+    const float4* stream; int nch;
+    MlpVec mlp; const float* w2_gate; float b2_gate; const float* Vr;
+    long long N;
+    const float *s, *v; float* out;
+};
+
+// launchers (painn_kernels.hip).  F = 32*NB; return hipError_t of the launch.
+hipError_t launch_embed(int NB, int nseg, const EmbedParams& p, hipStream_t st);
+hipError_t launch_edge(int NB, bool first, bool last, const EdgeParams& p, hipStream_t st);
+hipError_t launch_update(int NB, bool has_next, const UpdateParams& p, hipStream_t st);
+hipError_t launch_readout(int NB, const ReadoutParams& p, hipStream_t st);
+hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
+
+// ---- adw (adw_kernels.hip).  One kernel evaluates  Linear(3->H), SiLU, [Linear(H->H), SiLU] x n_hidden, Linear(H->1)
+// on rows (a0, a1, a2):  a0 = x[r];  a1 = in1 ? in1[r] : t;  a2 = idx ? emb[idx[r]] : emb ? emb[r] : t.
+struct AdwParams {
+    const float4* stream; int nch;          // hidden layers, 32-output chunks, layer-major
+    const float *w_in, *b_in;               // [H][3], [H]
+    const float* b_hidden;                  // [n_hidden][H]
+    const float* w_out; float b_out;        // [H], scalar
+    int n_hidden; long long B;
+    const float* x; const float* in1; const float* emb; const int32_t* idx;
+    float t;
+    float* out;
+};
+hipError_t launch_adw(int NB, const AdwParams& p, hipStream_t st);
+hipError_t configure_adw_kernels(int NB);
+
+// ---- integrator kernels (integrate_kernels.hip)
+hipError_t launch_axpy(float* y, const float* x, float a, const float* b, long long n, hipStream_t st);          // y = x + a*b
+hipError_t launch_heun(float* x, float hdt, const float* b1, const float* b2, long long n, hipStream_t st);      // x += hdt*(b1+b2)
+hipError_t launch_noise(float* x, float sigma, uint64_t seed, long long traj0, int step, long long B, int comps_per_traj,
+                        int atoms_for_com /*0 = no COM removal*/, hipStream_t st);
+hipError_t launch_selftest(float* out /*[64*16]*/, hipStream_t st);
+hipError_t launch_nan_check(const float* x, long long n, int* flag, hipStream_t st);
+
+// ---- host-side weight packing (pack.cpp)
+// One chunk = 32 output rows [row0, row0+32) x F_in = 32*NBin input columns [col0, col0+F_in) of a row-major W[out][ld],
+// laid out [k-step/4][lane][4]:  chunk[(4*nbi+g)*64 + l][q] = W[row0 + (l&31)][col0 + 32*nbi + 8*g + 4*(l>>5) + q].
+// Rows >= n_rows are zero-filled.
+void pack_chunk(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBin);
+
+}  // namespace ti
