@@ -14,18 +14,26 @@ from . import weights as W
 
 
 def time_grid(start: float, end: float, n_step: int) -> np.ndarray:
-    """float32 grid with the values of ``torch.linspace(start, end, n_step)`` (the reference grid,
-    /root/reference/mdqm9/thermo/ambient/integrators.py:43): torch fills the first half as start + i*step and the
-    second half as end - (n-1-i)*step, in float32."""
+    """The reference grid ``torch.linspace(start, end, n_step)`` as float32
+    (/root/reference/mdqm9/thermo/ambient/integrators.py:43).  PyTorch is used for it when importable, so the values are
+    bit-identical to the reference's; otherwise the same two-sided formula is evaluated in numpy (within 1 ulp: torch's
+    vectorised kernel rounds ``start + step * i`` in two stages)."""
+    try:
+        import torch
+        return torch.linspace(float(start), float(end), int(n_step), dtype=torch.float32).numpy().copy()
+    except ImportError:
+        return _time_grid_numpy(start, end, n_step)
+
+
+def _time_grid_numpy(start: float, end: float, n_step: int) -> np.ndarray:
     start, end = np.float32(start), np.float32(end)
     if n_step == 1:
         return np.asarray([start], np.float32)
     step = np.float32((end - start) / np.float32(n_step - 1))
     i = np.arange(n_step, dtype=np.int64)
-    half = n_step // 2
     lo = start + step * i.astype(np.float32)
     hi = end - step * (n_step - 1 - i).astype(np.float32)
-    return np.where(i < half, lo, hi).astype(np.float32)
+    return np.where(i < n_step // 2, lo, hi).astype(np.float32)
 
 
 def _rollout_desc(scheme, t_grid, save_every, mem, eps, seed, traj_offset, com_free_noise):
