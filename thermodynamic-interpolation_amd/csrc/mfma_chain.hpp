@@ -85,19 +85,24 @@ struct Pipe {
     }
 };
 
+// The weight float4 of k-group s+1 is read from LDS before the 4 MFMAs of group s are issued, so the ds_read latency
+// hides behind 256 cycles of matrix work instead of stalling every 4th MFMA.
 // acc[n][row] += sum_k W[n][k] * in[row][k]      (transposed product; acc is one 32-feature output block)
 template <int NB>
 __device__ __forceinline__ void gemm_bt(f32x16& acc, const Act<NB>& in, const f32x4* wl, int lane)
 {
+    f32x4 w = wl[lane];
 #pragma unroll
     for (int nbi = 0; nbi < NB; ++nbi)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 w = wl[(nbi * 4 + g) * 64 + lane];
+            const int nxt = nbi * 4 + g + 1;
+            const f32x4 wn = wl[(nxt < 4 * NB ? nxt : 0) * 64 + lane];
             acc = mfma32(w.x, in.b[nbi][4 * g + 0], acc);
             acc = mfma32(w.y, in.b[nbi][4 * g + 1], acc);
             acc = mfma32(w.z, in.b[nbi][4 * g + 2], acc);
             acc = mfma32(w.w, in.b[nbi][4 * g + 3], acc);
+            w = wn;
         }
 }
 
@@ -105,37 +110,18 @@ __device__ __forceinline__ void gemm_bt(f32x16& acc, const Act<NB>& in, const f3
 template <int NB>
 __device__ __forceinline__ void gemm_fl(f32x16& acc, const Act<NB>& in, const f32x4* wl, int lane)
 {
+    f32x4 w = wl[lane];
 #pragma unroll
     for (int nbi = 0; nbi < NB; ++nbi)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 w = wl[(nbi * 4 + g) * 64 + lane];
+            const int nxt = nbi * 4 + g + 1;
+            const f32x4 wn = wl[(nxt < 4 * NB ? nxt : 0) * 64 + lane];
             acc = mfma32(in.b[nbi][4 * g + 0], w.x, acc);
             acc = mfma32(in.b[nbi][4 * g + 1], w.y, acc);
             acc = mfma32(in.b[nbi][4 * g + 2], w.z, acc);
             acc = mfma32(in.b[nbi][4 * g + 3], w.w, acc);
-        }
-}
-
-// two independent flipped products sharing the k loop (phi and w output chunks): keeps two MFMA chains in flight
-template <int NB>
-__device__ __forceinline__ void gemm_fl2(f32x16& acc0, const Act<NB>& in0, const f32x4* wl0, f32x16& acc1, const Act<NB>& in1,
-                                         const f32x4* wl1, int lane)
-{
-#pragma unroll
-    for (int nbi = 0; nbi < NB; ++nbi)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 w0 = wl0[(nbi * 4 + g) * 64 + lane];
-            const f32x4 w1 = wl1[(nbi * 4 + g) * 64 + lane];
-            acc0 = mfma32(in0.b[nbi][4 * g + 0], w0.x, acc0);
-            acc1 = mfma32(in1.b[nbi][4 * g + 0], w1.x, acc1);
-            acc0 = mfma32(in0.b[nbi][4 * g + 1], w0.y, acc0);
-            acc1 = mfma32(in1.b[nbi][4 * g + 1], w1.y, acc1);
-            acc0 = mfma32(in0.b[nbi][4 * g + 2], w0.z, acc0);
-            acc1 = mfma32(in1.b[nbi][4 * g + 2], w1.z, acc1);
-            acc0 = mfma32(in0.b[nbi][4 * g + 3], w0.w, acc0);
-            acc1 = mfma32(in1.b[nbi][4 * g + 3], w1.w, acc1);
+            w = wn;
         }
 }
 
@@ -207,9 +193,31 @@ __device__ __forceinline__ void ln_silu(Act<NB>& a, const float* __restrict__ ga
     }
 }
 
+// sin and cos of an fp32 angle, abs error <= 2.2e-7 for |a| < 4096 (7e-8 below 300; checked against fp64 on 12M samples): Cody-Waite reduction by pi/2 with a 3-term fp32 split (each step an
+// exact-product fma) and the fdlibm k_sinf/k_cosf minimax polynomials on [-pi/4, pi/4].  The ocml sincosf is ~5x more
+// instructions because of its Payne-Hanek path; it is kept for the (never observed) huge-argument case.
+__device__ __forceinline__ void sincos_cw(float a, float& s, float& c)
+{
+    if (__builtin_expect(fabsf(a) > 4096.0f, 0)) { sincosf(a, &s, &c); return; }
+    const float n = rintf(a * 0.63661977236758134308f);
+    float r = fmaf(-n, 1.5707855225e+00f, a);
+    r = fmaf(-n, 1.0804334124e-05f, r);
+    r = fmaf(-n, 6.0770999344e-11f, r);
+    const float z = r * r;
+    const float ps = fmaf(z, fmaf(z, fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f), 8.3333293858894631756e-3f),
+                          -1.66666666416265235595e-1f);
+    const float pc = fmaf(z, fmaf(z, fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f), 4.16666233237390631894e-2f),
+                          -4.99999997251031003120e-1f);
+    const float sr = fmaf(r * z, ps, r), cr = fmaf(z, pc, 1.0f);
+    const int q = (int)n;
+    const float ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // PositionalEncoder (/root/reference/mdqm9/thermo/ambient/models/embedding.py:127-160) of one scalar per row, written
 // straight into the register layout: features 4m..4m+3 = cos(a(2m+1)), sin(a(2m+1)), cos(a(2m+2)), sin(a(2m+2)) with
-// a(k) = ((x / max_length) * k) * pi evaluated left to right in fp32 like the reference.
+// a(k) = ((x / max_length) * k) * pi evaluated left to right in fp32 like the reference (so the ARGUMENT is bit-identical).
 template <int NB>
 __device__ __forceinline__ void posenc_set(Act<NB>& a, float x_over_len, int h)
 {
@@ -220,8 +228,8 @@ __device__ __forceinline__ void posenc_set(Act<NB>& a, float x_over_len, int h)
         for (int g = 0; g < 4; ++g) {
             const int m = 8 * nb + 2 * g + h;
             float s1, c1, s2, c2;
-            sincosf((x_over_len * (float)(2 * m + 1)) * PI_F, &s1, &c1);
-            sincosf((x_over_len * (float)(2 * m + 2)) * PI_F, &s2, &c2);
+            sincos_cw((x_over_len * (float)(2 * m + 1)) * PI_F, s1, c1);
+            sincos_cw((x_over_len * (float)(2 * m + 2)) * PI_F, s2, c2);
             a.b[nb][4 * g + 0] = c1; a.b[nb][4 * g + 1] = s1; a.b[nb][4 * g + 2] = c2; a.b[nb][4 * g + 3] = s2;
         }
 }

@@ -9,6 +9,8 @@
 //
 // All dense layers run on v_mfma_f32_32x32x2_f32 through mfma_chain.hpp; activations never leave registers inside an
 // MLP chain; per-atom sums over incoming edges are done inside one wave in a fixed order (deterministic, no atomics).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 #include "mfma_chain.hpp"
 #include "ti_internal.hpp"
 
@@ -19,7 +21,7 @@ struct Cfg {
     static constexpr int F = 32 * NB;
     static constexpr int T = 64 * WAVES;
     static constexpr int CH4 = 256 * NB;
-    static constexpr size_t lds_bytes = 2 * (size_t)CH4 * 16 + (size_t)WAVES * 512;
+    static constexpr size_t lds_bytes = 2 * (size_t)CH4 * 16 + (size_t)WAVES * 512 + 21 * (size_t)F * 4;   // chunks, edge_dir scratch, layer vectors
 };
 
 // ================================================================================================== embed kernel
@@ -93,6 +95,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_embed_kernel(cons
 }
 
 // ================================================================================================== edge kernel
+// Per-layer vectors of the two message MLPs, copied once per workgroup into LDS (offsets in floats, F = n_features).
+// Global loads of bias/gamma/beta in front of every weight chunk exposed a full memory latency 56 times per row block.
+struct EV {
+    static constexpr int W_B0 = 0, W_G0 = 1, W_BE0 = 2, W_B1 = 3, W_G1 = 4, W_BE1 = 5, P_G0 = 6, P_BE0 = 7, P_B1 = 8, P_G1 = 9,
+                         P_BE1 = 10, P_B2 = 11, W_B2 = 16, COUNT = 21;      // x F
+};
+
 // sum over the 16 rows of this lane-half that belong to slot t, both halves combined (fixed order -> deterministic)
 __device__ __forceinline__ float slot_sum(const f32x16& q, const uint32_t (&mi)[16], int t)
 {
@@ -102,6 +111,11 @@ __device__ __forceinline__ float slot_sum(const f32x16& q, const uint32_t (&mi)[
     return a + xhalf(a);
 }
 
+// Fire-and-forget fp32 add (global_atomic_add_f32, no return): nothing waits for the memory round trip.  Every
+// accumulator element starts at zero and receives at most two adds per launch, both from the one wave that owns the
+// molecule (an atom's <= 31 incoming edges span at most two 32-row blocks), so the result does not depend on their order.
+__device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
+
 template <int NB, int WAVES, bool FIRST, bool LAST>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const EdgeParams p)
 {
@@ -109,9 +123,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const
     constexpr int F = C::F;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5;
-    Pipe<NB, C::T> pipe;
-    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);
     float* scratch = reinterpret_cast<float*>(lds + 2 * C::CH4) + wave * 128;      // [32 rows][4] edge_dir of the block
+    float* vec = reinterpret_cast<float*>(lds + 2 * C::CH4) + WAVES * 128;         // [EV::COUNT][F]
+    for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += C::T)
+        reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
+    Pipe<NB, C::T> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);               // barrier inside: vec is visible after it
 
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
@@ -124,6 +141,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const
         long long mol = gi * p.G + row_mol(meta);
         mol = mol < p.B ? mol : p.B - 1;
         const long long nsrc = mol * p.A + row_src(meta), ndst = mol * p.A + row_dst(meta);
+        const size_t erow0 = ((size_t)gi * p.nblk + blk) * 32;
+        // edge-state rows and P[src] are needed by the phi chain only: issue the loads now, use them after the w chain
+        Act<NB> ein;
+        if (FIRST) load_set(ein, p.edge_emb + row_type(meta) * F, h);
+        else       load_set(ein, p.e + (erow0 + j) * F, h);
+        Act<NB> pin;
+        load_set(pin, p.P + (size_t)nsrc * F, h);
         float dist;
         {
             const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
@@ -146,52 +170,45 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const
 #pragma unroll
                 for (int nbo = 0; nbo < NB; ++nbo) {
                     const f32x4* wl = pipe.begin();
-                    f32x16 a = load_block(p.w.b0, nbo, h);
+                    f32x16 a = load_block(vec + EV::W_B0 * F, nbo, h);
                     gemm_bt(a, enc, wl, lane);
                     g1.b[nbo] = a;
                     pipe.end();
                 }
             }
-            ln_silu(g1, p.w.g0, p.w.be0, h);
+            ln_silu(g1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, h);
 #pragma unroll
             for (int nbo = 0; nbo < NB; ++nbo) {
                 const f32x4* wl = pipe.begin();
-                f32x16 a = load_block(p.w.b1, nbo, h);
+                f32x16 a = load_block(vec + EV::W_B1 * F, nbo, h);
                 gemm_bt(a, g1, wl, lane);
                 g2.b[nbo] = a;
                 pipe.end();
             }
-            ln_silu(g2, p.w.g1, p.w.be1, h);
+            ln_silu(g2, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, h);
         }
         // ---- phi([s[src] | e]) hidden layers; the s[src] half of the first Linear is P[src] (node kernels)
-        const size_t erow0 = ((size_t)gi * p.nblk + blk) * 32;
         Act<NB> h2;
         {
             Act<NB> h1;
-            {
-                Act<NB> ein;
-                if (FIRST) load_set(ein, p.edge_emb + row_type(meta) * F, h);
-                else       load_set(ein, p.e + (erow0 + j) * F, h);
-                const float* prow = p.P + (size_t)nsrc * F;
-#pragma unroll
-                for (int nbo = 0; nbo < NB; ++nbo) {
-                    const f32x4* wl = pipe.begin();
-                    f32x16 a = load_block(prow, nbo, h);
-                    gemm_bt(a, ein, wl, lane);
-                    h1.b[nbo] = a;
-                    pipe.end();
-                }
-            }
-            ln_silu(h1, p.phi.g0, p.phi.be0, h);
 #pragma unroll
             for (int nbo = 0; nbo < NB; ++nbo) {
                 const f32x4* wl = pipe.begin();
-                f32x16 a = load_block(p.phi.b1, nbo, h);
+                f32x16 a = pin.b[nbo];
+                gemm_bt(a, ein, wl, lane);
+                h1.b[nbo] = a;
+                pipe.end();
+            }
+            ln_silu(h1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, h);
+#pragma unroll
+            for (int nbo = 0; nbo < NB; ++nbo) {
+                const f32x4* wl = pipe.begin();
+                f32x16 a = load_block(vec + EV::P_B1 * F, nbo, h);
                 gemm_bt(a, h1, wl, lane);
                 h2.b[nbo] = a;
                 pipe.end();
             }
-            ln_silu(h2, p.phi.g1, p.phi.be1, h);
+            ln_silu(h2, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, h);
         }
         // ---- output layer, flipped: features on lanes, the block's 32 rows in registers (row = acc_row(i, h))
         uint32_t mi[16];
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const
             const f32x4* wl1 = pipe.begin();
             gemm_fl(a1, g2, wl1, lane);
             pipe.end();
-            const float bp = p.phi.b2[c * F + 32 * nbo + fcol], bw = p.w.b2[c * F + 32 * nbo + fcol];
+            const float bp = vec[(EV::P_B2 + c) * F + 32 * nbo + fcol], bw = vec[(EV::W_B2 + c) * F + 32 * nbo + fcol];
             f32x16 r;
 #pragma unroll
             for (int i = 0; i < 16; ++i) r[i] = (a0[i] + bp) * (a1[i] + bw);
@@ -221,27 +238,37 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const
                 const float a = slot_sum(q, mi, t);
                 const int sn = slotnode[t];
                 const long long m2 = gi * p.G + (sn >> 8);
-                if (group_ok && m2 < p.B && h == 0) {
-                    float* q2 = dst + (size_t)(m2 * p.A + (sn & 255)) * stride;
-                    *q2 += a;
-                }
+                if (group_ok && m2 < p.B && h == 0) add_noret(dst + (size_t)(m2 * p.A + (sn & 255)) * stride, a);
             }
         };
 
 #pragma unroll 1
         for (int nbo = 0; nbo < NB; ++nbo) {
             const int fo = 32 * nbo + fcol;
-            {   // ds: invariant message, summed over incoming edges into s
+            // v[src] of the block's rows for the gated term: issued here, consumed after two more weight chunks
+            f32x16 vs[3];
+            if (!FIRST) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    long long m2 = gi * p.G + row_mol(mi[i]);
+                    m2 = m2 < p.B ? m2 : p.B - 1;
+                    const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[i])) * 3 * F + fo;
+                    vs[0][i] = vp[0]; vs[1][i] = vp[F]; vs[2][i] = vp[2 * F];
+                }
+            }
+            {   // ds: invariant message, summed over incoming edges
                 const f32x16 q = out_pair(2, nbo);
-                emit(q, p.s + fo, F);
+                emit(q, p.dsacc + fo, F);
             }
             if (!LAST) {   // de: edge state update  e += de
                 const f32x16 q = out_pair(3, nbo);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float* ep = p.e + (erow0 + acc_row(i, h)) * F + fo;
-                    const float eold = FIRST ? p.edge_emb[row_type(mi[i]) * F + fo] : *ep;
-                    if (group_ok) *ep = eold + q[i];
+                    if (group_ok) {
+                        if (FIRST) *ep = p.edge_emb[row_type(mi[i]) * F + fo] + q[i];
+                        else add_noret(ep, q[i]);
+                    }
                 }
             }
             {   // equivariant message: sum_e (sed * dir_e + gates * v[src_e]) -> dvacc ; sum_e cg * dir_e -> cacc
@@ -254,12 +281,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         q[i] = sed[i] * scratch[acc_row(i, h) * 4 + c];
-                        if (!FIRST) {
-                            long long m2 = gi * p.G + row_mol(mi[i]);
-                            m2 = m2 < p.B ? m2 : p.B - 1;
-                            const float vs = p.v[((size_t)(m2 * p.A + row_src(mi[i])) * 3 + c) * F + fo];
-                            q[i] = fmaf(gates[i], vs, q[i]);
-                        }
+                        if (!FIRST) q[i] = fmaf(gates[i], vs[c][i], q[i]);
                     }
                     emit(q, p.dvacc + c * F + fo, 3 * F);
                 }
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_update_kernel(con
     float* db = p.dvacc + nd * 3 * F;
     float* cb = p.cacc + nd * 3 * F;
     float* sb = p.s + nd * F;
+    float* ab = p.dsacc + nd * F;                 // sum of the invariant messages of this layer (edge kernel)
 
     // ---- phase A: v_eff = v + dvacc + cacc x v (parked in dvacc), n2 = |V v_eff|^2 over the 3 components
     Act<NB> n2;
@@ -345,7 +368,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_update_kernel(con
         }
         {
             Act<NB> ss;
-            load_set(ss, sb, h);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) ss.b[nb] = load_block(sb, nb, h) + load_block(ab, nb, h);      // s += ds
 #pragma unroll
             for (int nbo = 0; nbo < NB; ++nbo) {
                 const f32x4* wl = pipe.begin();
@@ -375,13 +399,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_update_kernel(con
         f32x16 a = load_block(p.mlp.b2 + 2 * F, nbo, h);
         gemm_bt(a, h2, wl, lane);
         pipe.end();
-        f32x16 so = load_block(sb, nbo, h);
+        f32x16 so = load_block(sb, nbo, h) + load_block(ab, nbo, h);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float n = sqrtf(n2.b[nbo][i]);
             so[i] = so[i] + ((n * n) * q[i] + a[i]);                  // s += vv_norm**2 * scale + add
         }
-        if (ok) store_block(sb, nbo, h, so);
+        if (ok) {
+            store_block(sb, nbo, h, so);
+            store_block(ab, nbo, h, f32x16{0});
+        }
     }
     Act<NB> gg;
 #pragma unroll

@@ -82,7 +82,7 @@ struct ti_handle {
     Stream st_embed{}, st_readout{}; std::vector<Stream> st_edge, st_update;
     DevBuf<uint32_t> rows; DevBuf<int32_t> slotnode, nslots, atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
-    DevBuf<float> x, cond, s, P, v, dvacc, cacc, e, b1, b2, xt;
+    DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs;
     int tap = -1; long long last_B = 0;
 
     // ---- adw
@@ -207,6 +207,15 @@ void pack_painn(ti_handle* h, const float* wts)
     layer(h->readout.W0, F, F, 0); layer(h->readout.W1, F, F, 0);
     h->st_readout = end_stream(o);
     h->packed.upload(pk);
+    // per-layer vector block of the edge kernel (order = struct EV in painn_kernels.hip)
+    std::vector<float> ev;
+    for (int l = 0; l < L; ++l) {
+        const MlpOff &w = h->w[l], &ph = h->phi[l];
+        for (size_t off : {w.b0, w.g0, w.be0, w.b1, w.g1, w.be1, ph.g0, ph.be0, ph.b1, ph.g1, ph.be1}) ev.insert(ev.end(), wts + off, wts + off + F);
+        ev.insert(ev.end(), wts + ph.b2, wts + ph.b2 + 5 * F);
+        ev.insert(ev.end(), wts + w.b2, wts + w.b2 + 5 * F);
+    }
+    h->edge_vecs.upload(ev);
 }
 
 void ensure_painn_ws(ti_handle* h, long long B)
@@ -217,7 +226,7 @@ void ensure_painn_ws(ti_handle* h, long long B)
     h->x.alloc(N * 3); h->b1.alloc(N * 3); h->b2.alloc(N * 3); h->xt.alloc(N * 3);
     h->cond.alloc(std::max<size_t>(N * h->ncond, 1));
     h->s.alloc(N * F); h->P.alloc(N * F);
-    h->v.alloc(N * 3 * F); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F);
+    h->v.alloc(N * 3 * F); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F); h->dsacc.alloc(N * F);
     h->e.alloc(std::max<size_t>(groups * h->nblk * 32 * F, 1));
     h->cap = B;
 }
@@ -232,6 +241,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     HIP_CHECK(hipMemsetAsync(h->v.p, 0, vbytes, st));
     HIP_CHECK(hipMemsetAsync(h->dvacc.p, 0, vbytes, st));
     HIP_CHECK(hipMemsetAsync(h->cacc.p, 0, vbytes, st));
+    HIP_CHECK(hipMemsetAsync(h->dsacc.p, 0, (size_t)N * F * sizeof(float), st));
     {
         EmbedParams p{};
         p.stream = h->S(h->st_embed); p.nch = h->st_embed.nch; p.mlp = h->vec(h->embed);
@@ -247,10 +257,10 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     for (int l = 0; l < L; ++l) {
         if (h->nblk > 0) {
             EdgeParams p{};
-            p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.phi = h->vec(h->phi[l]); p.w = h->vec(h->w[l]);
+            p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
             p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p; p.nslots = h->nslots.p;
             p.nblk = h->nblk; p.G = h->G; p.A = A; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
-            p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.s = h->s.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
+            p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
             HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, p, st));
         }
@@ -259,7 +269,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             UpdateParams p{};
             p.stream = h->S(h->st_update[l]); p.nch = h->st_update[l].nch; p.mlp = h->vec(h->upd[l]);
             p.pb0_next = l + 1 < L ? h->F(h->phi[l + 1].b0) : nullptr;
-            p.N = N; p.s = h->s.p; p.v = h->v.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.P = h->P.p;
+            p.N = N; p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.P = h->P.p;
             Timed tm(h, TI_KERNEL_PAINN_UPDATE);
             HIP_CHECK(launch_update(NB, l + 1 < L, p, st));
         }
@@ -539,7 +549,10 @@ int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)
         HIP_CHECK(hipStreamSynchronize(h->stream));
         if (what == 0) {
             if (n_floats != N * F) return fail(TI_E_ARG, "size mismatch (s)");
+            std::vector<float> ds(n_floats);                  // pending invariant messages (zero after an update stage)
             HIP_CHECK(hipMemcpy(out, h->s.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(ds.data(), h->dsacc.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n_floats; ++i) out[i] += ds[i];
         } else if (what == 1) {
             // v as the reference sees it at the tap: v + dvacc + cacc x v (the accumulators are zero after an update stage)
             if (n_floats != N * 3 * F) return fail(TI_E_ARG, "size mismatch (v)");

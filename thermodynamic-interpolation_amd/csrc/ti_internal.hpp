@@ -29,7 +29,7 @@ struct MlpVec {           // natural-order per-feature vectors of one reference 
 
 struct EdgeParams {
     const float4* stream; int nch;         // packed weight chunks of this layer's message block
-    MlpVec phi, w;                          // phi.b0 is folded into P by the node kernels
+    const float* vecs;                      // [21][F] bias/gamma/beta of the w and phi MLPs (painn_kernels.hip: struct EV)
     const float* edge_emb;                  // [4][F]  (first layer: e = edge_emb[type])
     const uint32_t* rows; const int32_t* slotnode; const int32_t* nslots;
     int nblk, G, A;
@@ -38,7 +38,7 @@ struct EdgeParams {
     const float* x;                         // [B*A][3]
     const float* P;                         // [B*A][F]   s @ W0[:, :F]^T + b0
     const float* v;                         // [B*A][3][F]
-    float* s;                               // [B*A][F]   += sum ds
+    float* dsacc;                           // [B*A][F]   += sum ds   (added to s by the update kernel)
     float* dvacc;                           // [B*A][3][F] += sum (sed*dir + gates*v[src])
     float* cacc;                            // [B*A][3][F] += sum cg*dir   (crossed with v[dst] in the update kernel)
     float* e;                               // [n_groups*nblk*32][F]
@@ -57,7 +57,7 @@ struct UpdateParams {
     const float4* stream; int nch;
     MlpVec mlp; const float* pb0_next;
     long long N;
-    float *s, *v, *dvacc, *cacc, *P;
+    float *s, *v, *dsacc, *dvacc, *cacc, *P;
 };
 
 struct ReadoutParams {
