@@ -248,4 +248,112 @@ __device__ __forceinline__ float dot_set(const Act<NB>& a, const float* __restri
     return acc + xhalf(acc);
 }
 
+
+// ================================================================================================================
+// 16-row variant (namespace r16): the same chaining scheme on v_mfma_f32_16x16x4_f32 (same FLOP rate as 32x32x2).
+// A wave owns 16 rows; an activation set of F = 16*NBK features is NBK*4 VGPRs per lane -- half the registers of the
+// 32-row layout -- so several independent workgroups fit on a CU and hide each other's LayerNorm / wait phases.
+//   lane l = (j, q), j = l & 15 (row), q = l >> 4;  register (nb, r) holds feature 16*nb + 4*q + r  (float4 at 16nb+4q).
+//   accumulator of the flipped product: lane (n = l & 15, q) register r holds row 4*q + r.
+// A weight chunk is still 32 output features x F inputs (two 16-feature blocks), packed [blk][nbi][lane][4] with
+//   chunk[(blk*NBK + nbi)*64 + l][r] = W[row0 + 16*blk + (l&15)][col0 + 16*nbi + 4*(l>>4) + r]          (pack_chunk16).
+namespace r16 {
+
+template <int NBK>
+struct Act {
+    f32x4 b[NBK];
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// sum over the 4 lane-quarters that share a row (lanes j, j+16, j+32, j+48), fixed order
+__device__ __forceinline__ float xquarters(float v)
+{
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// two 16-feature output blocks of one chunk; the two accumulator chains are independent and interleaved, which covers the
+// 40-cycle dependent latency of the 32-cycle 16x16x4 MFMA
+template <int NBK>
+__device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Act<NBK>& in, const f32x4* wl, int lane)
+{
+    f32x4 w0 = wl[lane], w1 = wl[NBK * 64 + lane];
+#pragma unroll
+    for (int nbi = 0; nbi < NBK; ++nbi) {
+        const int nxt = nbi + 1 < NBK ? nbi + 1 : 0;
+        const f32x4 n0 = wl[nxt * 64 + lane], n1 = wl[(NBK + nxt) * 64 + lane];
+        acc0 = mfma16(w0.x, in.b[nbi].x, acc0); acc1 = mfma16(w1.x, in.b[nbi].x, acc1);
+        acc0 = mfma16(w0.y, in.b[nbi].y, acc0); acc1 = mfma16(w1.y, in.b[nbi].y, acc1);
+        acc0 = mfma16(w0.z, in.b[nbi].z, acc0); acc1 = mfma16(w1.z, in.b[nbi].z, acc1);
+        acc0 = mfma16(w0.w, in.b[nbi].w, acc0); acc1 = mfma16(w1.w, in.b[nbi].w, acc1);
+        w0 = n0; w1 = n1;
+    }
+}
+template <int NBK>
+__device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Act<NBK>& in, const f32x4* wl, int lane)
+{
+    f32x4 w0 = wl[lane], w1 = wl[NBK * 64 + lane];
+#pragma unroll
+    for (int nbi = 0; nbi < NBK; ++nbi) {
+        const int nxt = nbi + 1 < NBK ? nbi + 1 : 0;
+        const f32x4 n0 = wl[nxt * 64 + lane], n1 = wl[(NBK + nxt) * 64 + lane];
+        acc0 = mfma16(in.b[nbi].x, w0.x, acc0); acc1 = mfma16(in.b[nbi].x, w1.x, acc1);
+        acc0 = mfma16(in.b[nbi].y, w0.y, acc0); acc1 = mfma16(in.b[nbi].y, w1.y, acc1);
+        acc0 = mfma16(in.b[nbi].z, w0.z, acc0); acc1 = mfma16(in.b[nbi].z, w1.z, acc1);
+        acc0 = mfma16(in.b[nbi].w, w0.w, acc0); acc1 = mfma16(in.b[nbi].w, w1.w, acc1);
+        w0 = n0; w1 = n1;
+    }
+}
+
+__device__ __forceinline__ f32x4 load_block(const float* p, int nb, int q) { return *reinterpret_cast<const f32x4*>(p + 16 * nb + 4 * q); }
+__device__ __forceinline__ void store_block(float* p, int nb, int q, const f32x4& v) { *reinterpret_cast<f32x4*>(p + 16 * nb + 4 * q) = v; }
+template <int NBK>
+__device__ __forceinline__ void load_set(Act<NBK>& a, const float* p, int q)
+{
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) a.b[nb] = load_block(p, nb, q);
+}
+
+template <int NBK>
+__device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const float* beta, int q)
+{
+    constexpr float invF = 1.0f / (16.0f * NBK);
+    float sum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) sum += (a.b[nb].x + a.b[nb].y) + (a.b[nb].z + a.b[nb].w);
+    const float mean = xquarters(sum) * invF;
+    float var = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = a.b[nb][r] - mean;
+            var = fmaf(d, d, var);
+        }
+    const float rstd = 1.0f / sqrtf(xquarters(var) * invF + 1e-5f);
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const f32x4 gm = load_block(gamma, nb, q), bt = load_block(beta, nb, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.b[nb][r] = silu(fmaf((a.b[nb][r] - mean) * rstd, gm[r], bt[r]));
+    }
+}
+
+template <int NBK>
+__device__ __forceinline__ void posenc_set(Act<NBK>& a, float x_over_len, int q)
+{
+    constexpr float PI_F = 3.14159265358979323846f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const int m = 4 * nb + q;
+        float s1, c1, s2, c2;
+        sincos_cw((x_over_len * (float)(2 * m + 1)) * PI_F, s1, c1);
+        sincos_cw((x_over_len * (float)(2 * m + 2)) * PI_F, s2, c2);
+        a.b[nb] = f32x4{c1, s1, c2, s2};
+    }
+}
+
+}  // namespace r16
+
 }  // namespace ti

@@ -21,7 +21,7 @@ struct Cfg {
     static constexpr int F = 32 * NB;
     static constexpr int T = 64 * WAVES;
     static constexpr int CH4 = 256 * NB;
-    static constexpr size_t lds_bytes = 2 * (size_t)CH4 * 16 + (size_t)WAVES * 512 + 21 * (size_t)F * 4;   // chunks, edge_dir scratch, layer vectors
+    static constexpr size_t lds_bytes = 2 * (size_t)CH4 * 16;     // node kernels: the two weight chunk buffers
 };
 
 // ================================================================================================== embed kernel
@@ -102,52 +102,56 @@ struct EV {
                          P_BE1 = 10, P_B2 = 11, W_B2 = 16, COUNT = 21;      // x F
 };
 
-// sum over the 16 rows of this lane-half that belong to slot t, both halves combined (fixed order -> deterministic)
-__device__ __forceinline__ float slot_sum(const f32x16& q, const uint32_t (&mi)[16], int t)
+// Fire-and-forget fp32 add (global_atomic_add_f32, no return): nothing waits for the memory round trip.  Every
+// accumulator element starts at zero and is only ever added to by the one wave that owns the molecule, in program
+// order (an atom's <= 31 incoming edges span at most three 16-row blocks of that wave).
+__device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// sum over the 4 rows of this lane quarter that belong to slot t, then over the 4 quarters (fixed order -> deterministic)
+__device__ __forceinline__ float slot_sum(const f32x4& v, const uint32_t (&mi)[4], int t)
 {
     float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a += (row_slot(mi[i]) == t) ? q[i] : 0.f;
-    return a + xhalf(a);
+    for (int r = 0; r < 4; ++r) a += (row_slot(mi[r]) == t) ? v[r] : 0.f;
+    return r16::xquarters(a);
 }
 
-// Fire-and-forget fp32 add (global_atomic_add_f32, no return): nothing waits for the memory round trip.  Every
-// accumulator element starts at zero and receives at most two adds per launch, both from the one wave that owns the
-// molecule (an atom's <= 31 incoming edges span at most two 32-row blocks), so the result does not depend on their order.
-__device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
-
-template <int NB, int WAVES, bool FIRST, bool LAST>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const EdgeParams p)
+// One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
+// 4 waves per workgroup share the weight-chunk stream; 2 workgroups per CU (F <= 128) run out of phase and hide each
+// other's LayerNorm / reduction / wait phases behind matrix work.
+#ifndef TI_EDGE_OCC
+#define TI_EDGE_OCC 2
+#endif
+template <int NBK, bool FIRST, bool LAST>
+__global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_kernel(const EdgeParams p)
 {
-    using C = Cfg<NB, WAVES>;
-    constexpr int F = C::F;
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
     extern __shared__ f32x4 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5;
-    float* scratch = reinterpret_cast<float*>(lds + 2 * C::CH4) + wave * 128;      // [32 rows][4] edge_dir of the block
-    float* vec = reinterpret_cast<float*>(lds + 2 * C::CH4) + WAVES * 128;         // [EV::COUNT][F]
-    for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += C::T)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    float* scratch = reinterpret_cast<float*>(lds + 2 * CH4) + wave * 64;          // [16 rows][4] edge_dir of the block
+    float* vec = reinterpret_cast<float*>(lds + 2 * CH4) + WAVES * 64;             // [EV::COUNT][F]
+    for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    Pipe<NB, C::T> pipe;
+    Pipe<NB, T> pipe;
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);               // barrier inside: vec is visible after it
 
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
-    const int fcol = lane & 31;
 
     for (int blk = 0; blk < p.nblk; ++blk) {
-        // ---- K1 geometry of this lane's row (both halves compute the same row)
-        const uint32_t meta = p.rows[blk * 32 + j];
+        // ---- K1 geometry of this lane's row (the 4 quarters compute the same row)
+        const uint32_t meta = p.rows[blk * 16 + j];
         long long mol = gi * p.G + row_mol(meta);
         mol = mol < p.B ? mol : p.B - 1;
         const long long nsrc = mol * p.A + row_src(meta), ndst = mol * p.A + row_dst(meta);
-        const size_t erow0 = ((size_t)gi * p.nblk + blk) * 32;
-        // edge-state rows and P[src] are needed by the phi chain only: issue the loads now, use them after the w chain
-        Act<NB> ein;
-        if (FIRST) load_set(ein, p.edge_emb + row_type(meta) * F, h);
-        else       load_set(ein, p.e + (erow0 + j) * F, h);
-        Act<NB> pin;
-        load_set(pin, p.P + (size_t)nsrc * F, h);
+        const size_t erow0 = ((size_t)gi * p.nblk + blk) * 16;
+        // edge-state rows and P[src] feed the phi chain only: issue the loads now, use them after the w chain
+        A16 ein, pin;
+        if (FIRST) r16::load_set(ein, p.edge_emb + row_type(meta) * F, q);
+        else       r16::load_set(ein, p.e + (erow0 + j) * F, q);
+        r16::load_set(pin, p.P + (size_t)nsrc * F, q);
         float dist;
         {
             const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
@@ -155,144 +159,153 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_edge_kernel(const
             const float rz = p.x[nsrc * 3 + 2] - p.x[ndst * 3 + 2];
             dist = sqrtf(rx * rx + ry * ry + rz * rz);
             const float den = 1.0f + dist;                       // edge_dir = r / (1 + d)   (not a unit vector)
-            if (h == 0) {
+            if (q == 0) {
                 f32x4 dd = {rx / den, ry / den, rz / den, 0.f};
                 *reinterpret_cast<f32x4*>(scratch + j * 4) = dd;
             }
         }
         // ---- w(enc(d)) hidden layers
-        Act<NB> g2;
+        A16 g2;
         {
-            Act<NB> g1;
+            A16 g1;
             {
-                Act<NB> enc;
-                posenc_set(enc, dist / p.length_scale, h);
+                A16 enc;
+                r16::posenc_set(enc, dist / p.length_scale, q);
 #pragma unroll
-                for (int nbo = 0; nbo < NB; ++nbo) {
+                for (int c = 0; c < NB; ++c) {
                     const f32x4* wl = pipe.begin();
-                    f32x16 a = load_block(vec + EV::W_B0 * F, nbo, h);
-                    gemm_bt(a, enc, wl, lane);
-                    g1.b[nbo] = a;
+                    f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
+                    r16::gemm_bt(a0, a1, enc, wl, lane);
+                    g1.b[2 * c] = a0; g1.b[2 * c + 1] = a1;
                     pipe.end();
                 }
             }
-            ln_silu(g1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, h);
+            r16::ln_silu(g1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
 #pragma unroll
-            for (int nbo = 0; nbo < NB; ++nbo) {
+            for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.begin();
-                f32x16 a = load_block(vec + EV::W_B1 * F, nbo, h);
-                gemm_bt(a, g1, wl, lane);
-                g2.b[nbo] = a;
+                f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
+                r16::gemm_bt(a0, a1, g1, wl, lane);
+                g2.b[2 * c] = a0; g2.b[2 * c + 1] = a1;
                 pipe.end();
             }
-            ln_silu(g2, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, h);
+            r16::ln_silu(g2, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
         }
         // ---- phi([s[src] | e]) hidden layers; the s[src] half of the first Linear is P[src] (node kernels)
-        Act<NB> h2;
+        A16 h2;
         {
-            Act<NB> h1;
+            A16 h1;
 #pragma unroll
-            for (int nbo = 0; nbo < NB; ++nbo) {
+            for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.begin();
-                f32x16 a = pin.b[nbo];
-                gemm_bt(a, ein, wl, lane);
-                h1.b[nbo] = a;
+                f32x4 a0 = pin.b[2 * c], a1 = pin.b[2 * c + 1];
+                r16::gemm_bt(a0, a1, ein, wl, lane);
+                h1.b[2 * c] = a0; h1.b[2 * c + 1] = a1;
                 pipe.end();
             }
-            ln_silu(h1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, h);
+            r16::ln_silu(h1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
 #pragma unroll
-            for (int nbo = 0; nbo < NB; ++nbo) {
+            for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.begin();
-                f32x16 a = load_block(vec + EV::P_B1 * F, nbo, h);
-                gemm_bt(a, h1, wl, lane);
-                h2.b[nbo] = a;
+                f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
+                r16::gemm_bt(a0, a1, h1, wl, lane);
+                h2.b[2 * c] = a0; h2.b[2 * c + 1] = a1;
                 pipe.end();
             }
-            ln_silu(h2, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, h);
+            r16::ln_silu(h2, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
         }
-        // ---- output layer, flipped: features on lanes, the block's 32 rows in registers (row = acc_row(i, h))
-        uint32_t mi[16];
+        // ---- output layer, flipped: features on lanes (l & 15), the block's rows 4q + r in registers
+        uint32_t mi[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mi[i] = p.rows[blk * 32 + acc_row(i, h)];
+        for (int r = 0; r < 4; ++r) mi[r] = p.rows[blk * 16 + 4 * q + r];
         const int nslots = p.nslots[blk];
-        const int32_t* slotnode = p.slotnode + blk * 32;
+        const int32_t* slotnode = p.slotnode + blk * 16;
 
-        // (phi_c + b) * (w_c + b) for output chunk c (0 gates, 1 scale_edge_dir, 2 ds, 3 de, 4 cross gates), block nbo
-        auto out_pair = [&](int c, int nbo) -> f32x16 {
-            f32x16 a0 = {0}, a1 = {0};
+        // (phi_c + b) * (w_c + b) for output chunk c (0 gates, 1 scale_edge_dir, 2 ds, 3 de, 4 cross gates), 32 features
+        // fo .. fo+31 as two 16-feature blocks
+        auto out_pair = [&](int c, int nbo, f32x4& r0, f32x4& r1) {
+            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
             const f32x4* wl0 = pipe.begin();
-            gemm_fl(a0, h2, wl0, lane);
+            r16::gemm_fl(a0, a1, h2, wl0, lane);
             pipe.end();
             const f32x4* wl1 = pipe.begin();
-            gemm_fl(a1, g2, wl1, lane);
+            r16::gemm_fl(b0, b1, g2, wl1, lane);
             pipe.end();
-            const float bp = vec[(EV::P_B2 + c) * F + 32 * nbo + fcol], bw = vec[(EV::W_B2 + c) * F + 32 * nbo + fcol];
-            f32x16 r;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = (a0[i] + bp) * (a1[i] + bw);
-            return r;
+            const float* bp = vec + (EV::P_B2 + c) * F + 32 * nbo + j;
+            const float* bw = vec + (EV::W_B2 + c) * F + 32 * nbo + j;
+            r0 = (a0 + bp[0]) * (b0 + bw[0]);
+            r1 = (a1 + bp[16]) * (b1 + bw[16]);
         };
-        // add the per-slot sums of q into dst[node*stride] (dst already offset to component/feature)
-        auto emit = [&](const f32x16& q, float* dst, size_t stride) {
+        // add the per-slot sums of (v0 | v1) into dst[node*stride + {0,16}] (dst already offset to component / feature)
+        auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
             for (int t = 0; t < nslots; ++t) {
-                const float a = slot_sum(q, mi, t);
+                const float s0 = slot_sum(v0, mi, t), s1 = slot_sum(v1, mi, t);
                 const int sn = slotnode[t];
                 const long long m2 = gi * p.G + (sn >> 8);
-                if (group_ok && m2 < p.B && h == 0) add_noret(dst + (size_t)(m2 * p.A + (sn & 255)) * stride, a);
+                if (group_ok && m2 < p.B && q < 2) add_noret(dst + (size_t)(m2 * p.A + (sn & 255)) * stride + 16 * q, q ? s1 : s0);
             }
         };
 
 #pragma unroll 1
         for (int nbo = 0; nbo < NB; ++nbo) {
-            const int fo = 32 * nbo + fcol;
-            // v[src] of the block's rows for the gated term: issued here, consumed after two more weight chunks
-            f32x16 vs[3];
+            const int fo = 32 * nbo + j;
+            // v[src] of the block's rows for the gated term: issued here, consumed after four more weight chunks
+            f32x4 vs[3][2];
             if (!FIRST) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    long long m2 = gi * p.G + row_mol(mi[i]);
+                for (int r = 0; r < 4; ++r) {
+                    long long m2 = gi * p.G + row_mol(mi[r]);
                     m2 = m2 < p.B ? m2 : p.B - 1;
-                    const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[i])) * 3 * F + fo;
-                    vs[0][i] = vp[0]; vs[1][i] = vp[F]; vs[2][i] = vp[2 * F];
+                    const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16]; }
                 }
             }
             {   // ds: invariant message, summed over incoming edges
-                const f32x16 q = out_pair(2, nbo);
-                emit(q, p.dsacc + fo, F);
+                f32x4 v0, v1;
+                out_pair(2, nbo, v0, v1);
+                emit(v0, v1, p.dsacc + fo, F);
             }
             if (!LAST) {   // de: edge state update  e += de
-                const f32x16 q = out_pair(3, nbo);
+                f32x4 v0, v1;
+                out_pair(3, nbo, v0, v1);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float* ep = p.e + (erow0 + acc_row(i, h)) * F + fo;
+                for (int r = 0; r < 4; ++r) {
+                    float* ep = p.e + (erow0 + 4 * q + r) * F + fo;
                     if (group_ok) {
-                        if (FIRST) *ep = p.edge_emb[row_type(mi[i]) * F + fo] + q[i];
-                        else add_noret(ep, q[i]);
+                        if (FIRST) {
+                            const float* em = p.edge_emb + row_type(mi[r]) * F + fo;
+                            ep[0] = em[0] + v0[r]; ep[16] = em[16] + v1[r];
+                        } else { add_noret(ep, v0[r]); add_noret(ep + 16, v1[r]); }
                     }
                 }
             }
             {   // equivariant message: sum_e (sed * dir_e + gates * v[src_e]) -> dvacc ; sum_e cg * dir_e -> cacc
-                const f32x16 sed = out_pair(1, nbo);
-                f32x16 gates = {0};
-                if (!FIRST) gates = out_pair(0, nbo);
+                f32x4 sed0, sed1, gt0 = {0, 0, 0, 0}, gt1 = {0, 0, 0, 0};
+                out_pair(1, nbo, sed0, sed1);
+                if (!FIRST) out_pair(0, nbo, gt0, gt1);
+                f32x4 dir[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 4);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    f32x16 q;
+                    f32x4 v0, v1;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        q[i] = sed[i] * scratch[acc_row(i, h) * 4 + c];
-                        if (!FIRST) q[i] = fmaf(gates[i], vs[c][i], q[i]);
+                    for (int r = 0; r < 4; ++r) {
+                        v0[r] = sed0[r] * dir[r][c]; v1[r] = sed1[r] * dir[r][c];
+                        if (!FIRST) { v0[r] = fmaf(gt0[r], vs[c][0][r], v0[r]); v1[r] = fmaf(gt1[r], vs[c][1][r], v1[r]); }
                     }
-                    emit(q, p.dvacc + c * F + fo, 3 * F);
+                    emit(v0, v1, p.dvacc + c * F + fo, 3 * F);
                 }
                 if (!FIRST) {
-                    const f32x16 cg = out_pair(4, nbo);
+                    f32x4 cg0, cg1;
+                    out_pair(4, nbo, cg0, cg1);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        f32x16 q;
+                        f32x4 v0, v1;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) q[i] = cg[i] * scratch[acc_row(i, h) * 4 + c];
-                        emit(q, p.cacc + c * F + fo, 3 * F);
+                        for (int r = 0; r < 4; ++r) { v0[r] = cg0[r] * dir[r][c]; v1[r] = cg1[r] * dir[r][c]; }
+                        emit(v0, v1, p.cacc + c * F + fo, 3 * F);
                     }
                 }
             }
@@ -508,6 +521,9 @@ static hipError_t set_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// edge kernel LDS: two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors
+static size_t edge_lds_bytes(int NB) { return 2 * (size_t)256 * NB * 16 + 4 * 256 + 21 * (size_t)32 * NB * 4; }
+
 template <int NB, int WAVES>
 static hipError_t configure_nb()
 {
@@ -515,8 +531,11 @@ static hipError_t configure_nb()
     hipError_t e;
 #define TI_SET(k) if ((e = set_lds(k, b)) != hipSuccess) return e
     TI_SET((painn_embed_kernel<NB, WAVES, 2>)); TI_SET((painn_embed_kernel<NB, WAVES, 3>)); TI_SET((painn_embed_kernel<NB, WAVES, 4>));
-    TI_SET((painn_edge_kernel<NB, WAVES, true, false>)); TI_SET((painn_edge_kernel<NB, WAVES, false, false>));
-    TI_SET((painn_edge_kernel<NB, WAVES, false, true>)); TI_SET((painn_edge_kernel<NB, WAVES, true, true>));
+    const size_t be = edge_lds_bytes(NB);
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true>, be)) != hipSuccess) return e;
     TI_SET((painn_update_kernel<NB, WAVES, true>)); TI_SET((painn_update_kernel<NB, WAVES, false>));
     TI_SET((painn_readout_kernel<NB, WAVES>));
 #undef TI_SET
@@ -563,12 +582,13 @@ hipError_t launch_embed(int NBv, int nseg, const EmbedParams& p, hipStream_t st)
 hipError_t launch_edge(int NBv, bool first, bool last, const EdgeParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
-        const dim3 g((unsigned)((p.n_groups + WAVES - 1) / WAVES));
-        const size_t l = Cfg<NB, WAVES>::lds_bytes;
-        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<NB, WAVES, true, true>), g, dim3(64 * WAVES), l, st, p);
-        else if (first) hipLaunchKernelGGL((painn_edge_kernel<NB, WAVES, true, false>), g, dim3(64 * WAVES), l, st, p);
-        else if (last) hipLaunchKernelGGL((painn_edge_kernel<NB, WAVES, false, true>), g, dim3(64 * WAVES), l, st, p);
-        else hipLaunchKernelGGL((painn_edge_kernel<NB, WAVES, false, false>), g, dim3(64 * WAVES), l, st, p);
+        (void)WAVES;
+        const dim3 g((unsigned)((p.n_groups + 3) / 4));          // 4 waves (= 4 molecule groups) per workgroup
+        const size_t l = edge_lds_bytes(NB);
+        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true>), g, dim3(256), l, st, p);
+        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false>), g, dim3(256), l, st, p);
+        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true>), g, dim3(256), l, st, p);
+        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false>), g, dim3(256), l, st, p);
     });
     return hipGetLastError();
 }

@@ -36,6 +36,20 @@ void pack_chunk(std::vector<float>& dst, const float* W, int ld, int n_rows, int
                 }
 }
 
+// 16-row kernels (mfma_chain.hpp, namespace r16): chunk[(blk*NBK + nbi)*64 + l][r] = W[row0 + 16*blk + (l&15)][col0 + 16*nbi + 4*(l>>4) + r]
+void pack_chunk16(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBK)
+{
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)2 * NBK * 64 * 4);
+    for (int blk = 0; blk < 2; ++blk)
+        for (int nbi = 0; nbi < NBK; ++nbi)
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * blk + (l & 15), col = col0 + 16 * nbi + 4 * (l >> 4) + r;
+                    dst[base + ((size_t)(blk * NBK + nbi) * 64 + l) * 4 + r] = row < n_rows ? W[(size_t)row * ld + col] : 0.f;
+                }
+}
+
 struct MlpOff { size_t W0, b0, g0, be0, W1, b1, g1, be1, W2, b2; int f_in, f_h, f_out; };
 static size_t take_mlp(MlpOff& m, size_t o, int f_in, int f_h, int f_out)
 {
@@ -132,27 +146,29 @@ void build_template(ti_handle* h, const int32_t* src, const int32_t* dst, const 
     std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) {
         return dst[a] != dst[b] ? dst[a] < dst[b] : src[a] < src[b];
     });
+    // the edge kernel walks a group in blocks of RB = 16 rows
     // group size: smallest G in 1..8 whose padding waste is <= 2 %, else the least wasteful
+    constexpr int RB = ti::EDGE_ROWS_PER_BLOCK;
     int bestG = 1; double bestW = 2.0;
     for (int G = 1; G <= 8 && E > 0; ++G) {
-        const int rows = G * E, padded = (rows + 31) / 32 * 32;
+        const int rows = G * E, padded = (rows + RB - 1) / RB * RB;
         const double waste = double(padded - rows) / padded;
         if (waste < bestW - 1e-12) { bestW = waste; bestG = G; }
         if (waste <= 0.02) { bestG = G; break; }
     }
     h->G = bestG;
     const int rows = h->G * E;
-    h->nblk = (rows + 31) / 32;
-    std::vector<uint32_t> rw((size_t)h->nblk * 32, (uint32_t)63 << 18);
-    std::vector<int32_t> sn((size_t)h->nblk * 32, -1), ns(std::max(h->nblk, 1), 0);
+    h->nblk = (rows + RB - 1) / RB;
+    std::vector<uint32_t> rw((size_t)std::max(h->nblk, 1) * RB, (uint32_t)63 << 18);
+    std::vector<int32_t> sn((size_t)std::max(h->nblk, 1) * RB, -1), ns(std::max(h->nblk, 1), 0);
     for (int blk = 0; blk < h->nblk; ++blk) {
         int nslot = 0, last_key = -1;
-        for (int j = 0; j < 32; ++j) {
-            const int r = blk * 32 + j;
+        for (int j = 0; j < RB; ++j) {
+            const int r = blk * RB + j;
             if (r >= rows) break;
             const int m = r / E, k = h->perm[r % E];
             const int key = m * 256 + dst[k];
-            if (key != last_key) { sn[(size_t)blk * 32 + nslot] = (m << 8) | dst[k]; ++nslot; last_key = key; }
+            if (key != last_key) { sn[(size_t)blk * RB + nslot] = (m << 8) | dst[k]; ++nslot; last_key = key; }
             rw[r] = 1u | ((uint32_t)m << 1) | ((uint32_t)src[k] << 6) | ((uint32_t)dst[k] << 11) | ((uint32_t)etype[k] << 16) |
                     ((uint32_t)(nslot - 1) << 18);
         }
@@ -178,16 +194,18 @@ void pack_painn(ti_handle* h, const float* wts)
     h->st_embed = end_stream(o);
     for (int l = 0; l < L; ++l) {
         const bool first = l == 0, last = l == L - 1;
-        o = begin_stream();
-        layer(h->w[l].W0, F, F, 0); layer(h->w[l].W1, F, F, 0);
-        layer(h->phi[l].W0, 2 * F, F, F);          // the e half of [s[src] | e]
-        layer(h->phi[l].W1, F, F, 0);
+        o = begin_stream();                          // edge kernel: 16-row chunk format
+        const int NBK = F / 16;
+        auto layer16 = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) pack_chunk16(pk, wts + W, ld, n_rows, 32 * nbo, col0, NBK); };
+        layer16(h->w[l].W0, F, F, 0); layer16(h->w[l].W1, F, F, 0);
+        layer16(h->phi[l].W0, 2 * F, F, F);        // the e half of [s[src] | e]
+        layer16(h->phi[l].W1, F, F, 0);
         for (int nbo = 0; nbo < NB; ++nbo)
             for (int c : {2, 3, 1, 0, 4}) {       // consumption order of painn_edge_kernel: ds, de, sed, gates, cross gates
                 if (c == 3 && last) continue;
                 if ((c == 0 || c == 4) && first) continue;
-                pack_chunk(pk, wts + h->phi[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NB);
-                pack_chunk(pk, wts + h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NB);
+                pack_chunk16(pk, wts + h->phi[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NBK);
+                pack_chunk16(pk, wts + h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NBK);
             }
         h->st_edge.push_back(end_stream(o));
         o = begin_stream();
@@ -227,7 +245,7 @@ void ensure_painn_ws(ti_handle* h, long long B)
     h->cond.alloc(std::max<size_t>(N * h->ncond, 1));
     h->s.alloc(N * F); h->P.alloc(N * F);
     h->v.alloc(N * 3 * F); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F); h->dsacc.alloc(N * F);
-    h->e.alloc(std::max<size_t>(groups * h->nblk * 32 * F, 1));
+    h->e.alloc(std::max<size_t>(groups * h->nblk * ti::EDGE_ROWS_PER_BLOCK * F, 1));
     h->cap = B;
 }
 
@@ -569,13 +587,13 @@ int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)
                     }
         } else if (what == 2) {
             if (n_floats != B * E * F) return fail(TI_E_ARG, "size mismatch (e)");
-            const size_t groups = (B + h->G - 1) / h->G, rows = groups * h->nblk * 32;
+            const size_t RB = ti::EDGE_ROWS_PER_BLOCK, groups = (B + h->G - 1) / h->G, rows = groups * h->nblk * RB;
             std::vector<float> e(rows * F);
             HIP_CHECK(hipMemcpy(e.data(), h->e.p, e.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (size_t m = 0; m < B; ++m)
                 for (size_t k = 0; k < E; ++k) {
                     const size_t gi = m / h->G, r = (m % h->G) * E + k;          // k = sorted position
-                    std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + (gi * h->nblk * 32 + r) * F, F * sizeof(float));
+                    std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + (gi * h->nblk * RB + r) * F, F * sizeof(float));
                 }
         } else return fail(TI_E_ARG, "unknown tap");
         return TI_OK;

@@ -12,11 +12,12 @@ namespace ti {
 
 // ---- molecule-group edge template -------------------------------------------------------------------------------
 // The E_m edges of one molecule are sorted by (dst, src); G molecules form a "group" whose G*E_m edge rows are padded
-// to NBLK blocks of 32 rows.  One wave owns one group, so every per-atom sum over incoming edges stays inside a wave
+// to NBLK blocks of EDGE_ROWS_PER_BLOCK rows.  One wave owns one group, so every per-atom sum over incoming edges stays inside a wave
 // (deterministic, no atomics).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots".
 //   row word : bit0 valid | mol_local<<1 (5b) | src<<6 (5b) | dst<<11 (5b) | etype<<16 (2b) | slot<<18 (6b, 63 = none)
 //   slot word: mol_local<<8 | atom     (-1 = unused)
 constexpr int ROW_VALID = 1;
+constexpr int EDGE_ROWS_PER_BLOCK = 16;     // painn_edge_kernel walks a group in 16-row blocks (16x16x4 MFMA)
 __host__ __device__ inline int row_mol(uint32_t w) { return (w >> 1) & 31; }
 __host__ __device__ inline int row_src(uint32_t w) { return (w >> 6) & 31; }
 __host__ __device__ inline int row_dst(uint32_t w) { return (w >> 11) & 31; }
@@ -41,7 +42,7 @@ struct EdgeParams {
     float* dsacc;                           // [B*A][F]   += sum ds   (added to s by the update kernel)
     float* dvacc;                           // [B*A][3][F] += sum (sed*dir + gates*v[src])
     float* cacc;                            // [B*A][3][F] += sum cg*dir   (crossed with v[dst] in the update kernel)
-    float* e;                               // [n_groups*nblk*32][F]
+    float* e;                               // [n_groups*nblk*16][F]
 };
 
 struct EmbedParams {
