@@ -62,7 +62,11 @@ struct Pipe {
     // start of a chunk: kick off the global load of the following chunk, return the LDS image of the current one
     __device__ __forceinline__ const f32x4* begin()
     {
+#ifdef TI_ABL_NOSTREAM          // ablation build (timing only): always re-read chunk 0 (L1/L2-hot), no weight streaming cost
+        const int next = 0;
+#else
         const int next = (idx + 1 == nch) ? 0 : idx + 1;
+#endif
         const f32x4* src = g + (size_t)next * CH4;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -193,16 +197,14 @@ __device__ __forceinline__ void ln_silu(Act<NB>& a, const float* __restrict__ ga
     }
 }
 
-// sin and cos of an fp32 angle, abs error <= 2.2e-7 for |a| < 4096 (7e-8 below 300; checked against fp64 on 12M samples): Cody-Waite reduction by pi/2 with a 3-term fp32 split (each step an
-// exact-product fma) and the fdlibm k_sinf/k_cosf minimax polynomials on [-pi/4, pi/4].  The ocml sincosf is ~5x more
-// instructions because of its Payne-Hanek path; it is kept for the (never observed) huge-argument case.
+// sin and cos of an fp32 angle, branch-free and accurate (~1 ulp) for any |a| < 2^30: the reduction a - n*pi/2 is done with
+// two fp64 FMAs (53-bit pi/2 split), then the fdlibm k_sinf/k_cosf minimax polynomials on [-pi/4, pi/4] in fp32.  The ocml
+// sincosf costs ~5x the instructions (Payne-Hanek path) and inlining it 16 times per row block blew the I-cache footprint.
 __device__ __forceinline__ void sincos_cw(float a, float& s, float& c)
 {
-    if (__builtin_expect(fabsf(a) > 4096.0f, 0)) { sincosf(a, &s, &c); return; }
     const float n = rintf(a * 0.63661977236758134308f);
-    float r = fmaf(-n, 1.5707855225e+00f, a);
-    r = fmaf(-n, 1.0804334124e-05f, r);
-    r = fmaf(-n, 6.0770999344e-11f, r);
+    const double nd = (double)n;
+    const float r = (float)fma(-nd, 6.123233995736766036e-17, fma(-nd, 1.57079632679489655800e+00, (double)a));
     const float z = r * r;
     const float ps = fmaf(z, fmaf(z, fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f), 8.3333293858894631756e-3f),
                           -1.66666666416265235595e-1f);

@@ -105,16 +105,11 @@ struct EV {
 // Fire-and-forget fp32 add (global_atomic_add_f32, no return): nothing waits for the memory round trip.  Every
 // accumulator element starts at zero and is only ever added to by the one wave that owns the molecule, in program
 // order (an atom's <= 31 incoming edges span at most three 16-row blocks of that wave).
+#ifdef TI_ABL_NOATOMIC          // ablation build (timing only, wrong results): keep the value alive, drop the memory op
+__device__ __forceinline__ void add_noret(float* p, float v) { asm volatile("" ::"v"(v), "v"(p)); }
+#else
 __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
-
-// sum over the 4 rows of this lane quarter that belong to slot t, then over the 4 quarters (fixed order -> deterministic)
-__device__ __forceinline__ float slot_sum(const f32x4& v, const uint32_t (&mi)[4], int t)
-{
-    float a = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a += (row_slot(mi[r]) == t) ? v[r] : 0.f;
-    return r16::xquarters(a);
-}
+#endif
 
 // One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
 // 4 waves per workgroup share the weight-chunk stream; 2 workgroups per CU (F <= 128) run out of phase and hide each
@@ -147,11 +142,6 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
         mol = mol < p.B ? mol : p.B - 1;
         const long long nsrc = mol * p.A + row_src(meta), ndst = mol * p.A + row_dst(meta);
         const size_t erow0 = ((size_t)gi * p.nblk + blk) * 16;
-        // edge-state rows and P[src] feed the phi chain only: issue the loads now, use them after the w chain
-        A16 ein, pin;
-        if (FIRST) r16::load_set(ein, p.edge_emb + row_type(meta) * F, q);
-        else       r16::load_set(ein, p.e + (erow0 + j) * F, q);
-        r16::load_set(pin, p.P + (size_t)nsrc * F, q);
         float dist;
         {
             const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
@@ -194,11 +184,14 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
         // ---- phi([s[src] | e]) hidden layers; the s[src] half of the first Linear is P[src] (node kernels)
         A16 h2;
         {
-            A16 h1;
+            A16 h1, ein;
+            if (FIRST) r16::load_set(ein, p.edge_emb + row_type(meta) * F, q);
+            else       r16::load_set(ein, p.e + (erow0 + j) * F, q);
+            const float* prow = p.P + (size_t)nsrc * F;
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.begin();
-                f32x4 a0 = pin.b[2 * c], a1 = pin.b[2 * c + 1];
+                f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
                 r16::gemm_bt(a0, a1, ein, wl, lane);
                 h1.b[2 * c] = a0; h1.b[2 * c + 1] = a1;
                 pipe.end();
@@ -218,8 +211,20 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
         uint32_t mi[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) mi[r] = p.rows[blk * 16 + 4 * q + r];
-        const int nslots = p.nslots[blk];
-        const int32_t* slotnode = p.slotnode + blk * 16;
+        // Per-atom sums over the block's rows as a 16x16 selection product on the matrix core:
+        //   S[slot][n] = sum_row Sel[slot][row] * val[row][n],  Sel[slot][row] = 1 if the row's destination is that slot.
+        // val is already in B-operand layout (lane (n, q) holds rows 4q + r); Sel in A-operand layout is sel[r] below.  The
+        // products are exact (x 1.0 or x 0.0) and the MFMA sums k in a fixed order, so the result is deterministic.  The
+        // output lands as lane (n, q), register r = slot 4q + r; sn[r] is that slot's atom (or -1).
+        f32x4 sel;
+        int snode[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sel[r] = (row_slot(mi[r]) == j) ? 1.0f : 0.0f;
+            const int sn = p.slotnode[blk * 16 + 4 * q + r];
+            const long long m2 = gi * p.G + (sn >> 8);
+            snode[r] = (sn >= 0 && group_ok && m2 < p.B) ? (int)(m2 * p.A + (sn & 255)) : -1;
+        }
 
         // (phi_c + b) * (w_c + b) for output chunk c (0 gates, 1 scale_edge_dir, 2 ds, 3 de, 4 cross gates), 32 features
         // fo .. fo+31 as two 16-feature blocks
@@ -238,29 +243,17 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
         };
         // add the per-slot sums of (v0 | v1) into dst[node*stride + {0,16}] (dst already offset to component / feature)
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
-            for (int t = 0; t < nslots; ++t) {
-                const float s0 = slot_sum(v0, mi, t), s1 = slot_sum(v1, mi, t);
-                const int sn = slotnode[t];
-                const long long m2 = gi * p.G + (sn >> 8);
-                if (group_ok && m2 < p.B && q < 2) add_noret(dst + (size_t)(m2 * p.A + (sn & 255)) * stride + 16 * q, q ? s1 : s0);
-            }
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s0 = r16::mfma16(sel[r], v0[r], s0); s1 = r16::mfma16(sel[r], v1[r], s1); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (snode[r] >= 0) { float* d = dst + (size_t)snode[r] * stride; add_noret(d, s0[r]); add_noret(d + 16, s1[r]); }
         };
 
 #pragma unroll 1
         for (int nbo = 0; nbo < NB; ++nbo) {
             const int fo = 32 * nbo + j;
-            // v[src] of the block's rows for the gated term: issued here, consumed after four more weight chunks
-            f32x4 vs[3][2];
-            if (!FIRST) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    long long m2 = gi * p.G + row_mol(mi[r]);
-                    m2 = m2 < p.B ? m2 : p.B - 1;
-                    const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16]; }
-                }
-            }
             {   // ds: invariant message, summed over incoming edges
                 f32x4 v0, v1;
                 out_pair(2, nbo, v0, v1);
@@ -283,7 +276,19 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
             {   // equivariant message: sum_e (sed * dir_e + gates * v[src_e]) -> dvacc ; sum_e cg * dir_e -> cacc
                 f32x4 sed0, sed1, gt0 = {0, 0, 0, 0}, gt1 = {0, 0, 0, 0};
                 out_pair(1, nbo, sed0, sed1);
-                if (!FIRST) out_pair(0, nbo, gt0, gt1);
+                // v[src] of the block's rows for the gated term: issued here, consumed after the two gate chunks
+                f32x4 vs[3][2];
+                if (!FIRST) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        long long m2 = gi * p.G + row_mol(mi[r]);
+                        m2 = m2 < p.B ? m2 : p.B - 1;
+                        const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16]; }
+                    }
+                    out_pair(0, nbo, gt0, gt1);
+                }
                 f32x4 dir[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 4);
