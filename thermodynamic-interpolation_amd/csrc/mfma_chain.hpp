@@ -38,40 +38,43 @@ __device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
 // ------------------------------------------------------------------------------------------------ weight chunk pipe
-// CH4 = float4 per chunk = 256*NB (KS = 16*NB k-steps x 64 lanes).  T = threads per workgroup.
-template <int NB, int T>
+// A "logical chunk" is 256*NB float4 (32 output features x F inputs).  SC logical chunks are staged per barrier interval
+// (a superchunk): the gap between two MFMA bursts -- drain, ds_write, barrier, first ds_reads -- is paid once per SC chunks.
+// T = threads per workgroup.  Usage: p = acquire(); ...GEMM on p...; release();   (uniform control flow only)
+template <int NB, int T, int SC = 1>
 struct Pipe {
-    static constexpr int CH4 = 256 * NB;
-    static constexpr int PER = (CH4 + T - 1) / T;
+    static constexpr int CH4 = 256 * NB;            // float4 per logical chunk
+    static constexpr int SUP4 = CH4 * SC;           // float4 per superchunk
+    static constexpr int PER = (SUP4 + T - 1) / T;
     const f32x4* __restrict__ g;
     f32x4* l[2];
-    int nch, idx, par;
+    int nsup, idx, par, sub;
     f32x4 st[PER];
 
     __device__ __forceinline__ void init(const f32x4* stream, int n_chunks, f32x4* lds)
     {
-        g = stream; nch = n_chunks; idx = 0; par = 0;
-        l[0] = lds; l[1] = lds + CH4;
+        g = stream; nsup = n_chunks / SC; idx = 0; par = 0; sub = 0;
+        l[0] = lds; l[1] = lds + SUP4;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int o = threadIdx.x + k * T;
-            if (CH4 % T == 0 || o < CH4) l[0][o] = g[o];
+            if (SUP4 % T == 0 || o < SUP4) l[0][o] = g[o];
         }
         __syncthreads();
     }
-    // start of a chunk: kick off the global load of the following chunk, return the LDS image of the current one
+    // start of a superchunk: kick off the global load of the following one, return the LDS image of the current one
     __device__ __forceinline__ const f32x4* begin()
     {
-#ifdef TI_ABL_NOSTREAM          // ablation build (timing only): always re-read chunk 0 (L1/L2-hot), no weight streaming cost
+#ifdef TI_ABL_NOSTREAM          // ablation build (timing only): always re-read superchunk 0, no weight streaming cost
         const int next = 0;
 #else
-        const int next = (idx + 1 == nch) ? 0 : idx + 1;
+        const int next = (idx + 1 == nsup) ? 0 : idx + 1;
 #endif
-        const f32x4* src = g + (size_t)next * CH4;
+        const f32x4* src = g + (size_t)next * SUP4;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int o = threadIdx.x + k * T;
-            if (CH4 % T == 0 || o < CH4) st[k] = src[o];
+            if (SUP4 % T == 0 || o < SUP4) st[k] = src[o];
         }
         return l[par];
     }
@@ -81,11 +84,73 @@ struct Pipe {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int o = threadIdx.x + k * T;
-            if (CH4 % T == 0 || o < CH4) dst[o] = st[k];
+            if (SUP4 % T == 0 || o < SUP4) dst[o] = st[k];
         }
         __syncthreads();
-        idx = (idx + 1 == nch) ? 0 : idx + 1;
+        idx = (idx + 1 == nsup) ? 0 : idx + 1;
         par ^= 1;
+    }
+    // logical-chunk cursor on top of begin()/end()
+    __device__ __forceinline__ const f32x4* acquire()
+    {
+        if (SC == 1) return begin();
+        if (sub == 0) cur = begin();
+        return cur + sub * CH4;
+    }
+    __device__ __forceinline__ void release()
+    {
+        if (SC == 1) { end(); return; }
+        if (++sub == SC) { end(); sub = 0; }
+    }
+    const f32x4* cur;
+};
+
+// LDS-DMA variant (global_load_lds_dwordx4): the next superchunk goes straight from L2 into the other LDS buffer -- no
+// staging registers, no ds_write.  The DMA is issued when the first logical chunk of the current superchunk is released
+// (hipcc drains vmcnt(0) at the next use of an ordinary global load while a DMA is in flight, so it is kept away from
+// the GEMM prologues), and is waited for at the superchunk's closing barrier.
+template <int NB, int T, int SC>
+struct PipeDMA {
+    static constexpr int CH4 = 256 * NB, SUP4 = CH4 * SC, PER = SUP4 / T;
+    static_assert(SUP4 % T == 0, "superchunk must be a multiple of the workgroup's 16-byte lanes");
+    const f32x4* __restrict__ g;
+    f32x4* base;
+    int nsup, idx, par, sub, wave, lane;
+
+    __device__ __forceinline__ void dma(const f32x4* src, f32x4* dst) const
+    {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int o = k * T + wave * 64;                 // wave-uniform LDS base; lane i lands at base + 16*i bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + o + lane),
+                                             (__attribute__((address_space(3))) void*)(dst + o), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void init(const f32x4* stream, int n_chunks, f32x4* lds, int wave_, int lane_)
+    {
+        g = stream; nsup = n_chunks / SC; idx = 0; par = 0; sub = 0; wave = wave_; lane = lane_;
+        base = lds;
+        dma(g, base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ const f32x4* acquire() const { return base + par * SUP4 + sub * CH4; }
+    __device__ __forceinline__ void release()
+    {
+        if (sub == 0) {
+#ifdef TI_ABL_NOSTREAM
+            const int next = 0;
+#else
+            const int next = (idx + 1 == nsup) ? 0 : idx + 1;
+#endif
+            dma(g + (size_t)next * SUP4, base + (par ^ 1) * SUP4);
+        }
+        if (++sub == SC) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            idx = (idx + 1 == nsup) ? 0 : idx + 1;
+            par ^= 1; sub = 0;
+        }
     }
 };
 

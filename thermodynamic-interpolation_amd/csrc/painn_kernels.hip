@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
     using A16 = r16::Act<NBK>;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    float* scratch = reinterpret_cast<float*>(lds + 2 * CH4) + wave * 64;          // [16 rows][4] edge_dir of the block
-    float* vec = reinterpret_cast<float*>(lds + 2 * CH4) + WAVES * 64;             // [EV::COUNT][F]
+    float* scratch = reinterpret_cast<float*>(lds + 4 * CH4) + wave * 64;          // [16 rows][4] edge_dir of the block
+    float* vec = reinterpret_cast<float*>(lds + 4 * CH4) + WAVES * 64;             // [EV::COUNT][F]
     for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    Pipe<NB, T> pipe;
-    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);               // barrier inside: vec is visible after it
+    PipeDMA<NB, T, 2> pipe;                                                      // weights staged two chunks per barrier
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);   // barrier inside: vec is visible after it
 
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
@@ -163,21 +163,21 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
                 r16::posenc_set(enc, dist / p.length_scale, q);
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
-                    const f32x4* wl = pipe.begin();
+                    const f32x4* wl = pipe.acquire();
                     f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
                     r16::gemm_bt(a0, a1, enc, wl, lane);
                     g1.b[2 * c] = a0; g1.b[2 * c + 1] = a1;
-                    pipe.end();
+                    pipe.release();
                 }
             }
             r16::ln_silu(g1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                const f32x4* wl = pipe.begin();
+                const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
                 r16::gemm_bt(a0, a1, g1, wl, lane);
                 g2.b[2 * c] = a0; g2.b[2 * c + 1] = a1;
-                pipe.end();
+                pipe.release();
             }
             r16::ln_silu(g2, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
         }
@@ -190,20 +190,20 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
             const float* prow = p.P + (size_t)nsrc * F;
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                const f32x4* wl = pipe.begin();
+                const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
                 r16::gemm_bt(a0, a1, ein, wl, lane);
                 h1.b[2 * c] = a0; h1.b[2 * c + 1] = a1;
-                pipe.end();
+                pipe.release();
             }
             r16::ln_silu(h1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                const f32x4* wl = pipe.begin();
+                const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
                 r16::gemm_bt(a0, a1, h1, wl, lane);
                 h2.b[2 * c] = a0; h2.b[2 * c + 1] = a1;
-                pipe.end();
+                pipe.release();
             }
             r16::ln_silu(h2, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
         }
@@ -230,12 +230,12 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
         // fo .. fo+31 as two 16-feature blocks
         auto out_pair = [&](int c, int nbo, f32x4& r0, f32x4& r1) {
             f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-            const f32x4* wl0 = pipe.begin();
+            const f32x4* wl0 = pipe.acquire();
             r16::gemm_fl(a0, a1, h2, wl0, lane);
-            pipe.end();
-            const f32x4* wl1 = pipe.begin();
+            pipe.release();
+            const f32x4* wl1 = pipe.acquire();
             r16::gemm_fl(b0, b1, g2, wl1, lane);
-            pipe.end();
+            pipe.release();
             const float* bp = vec + (EV::P_B2 + c) * F + 32 * nbo + j;
             const float* bw = vec + (EV::W_B2 + c) * F + 32 * nbo + j;
             r0 = (a0 + bp[0]) * (b0 + bw[0]);
@@ -526,8 +526,8 @@ static hipError_t set_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// edge kernel LDS: two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors
-static size_t edge_lds_bytes(int NB) { return 2 * (size_t)256 * NB * 16 + 4 * 256 + 21 * (size_t)32 * NB * 4; }
+// edge kernel LDS: two superchunks of two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors
+static size_t edge_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 4 * 256 + 21 * (size_t)32 * NB * 4; }
 
 template <int NB, int WAVES>
 static hipError_t configure_nb()
