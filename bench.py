@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
     ap.add_argument("--eps", type=float, default=0.01)
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x2"], help="matrix path of the message MLPs (DESIGN.md §3.4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512, help="molecules in the CPU-oracle sample")
     return ap.parse_args()
@@ -80,7 +81,7 @@ def main():
     syn, W = ti.synthetic, ti.weights
     template = syn.fully_connected_template(A)
     flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 0), W.painn_param_spec(W.AMBIENT, F, L, 25))
-    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *template, np.arange(A), flat, temp_length=100.0, device=local_rank)
+    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *template, np.arange(A), flat, temp_length=100.0, device=local_rank, precision=args.precision)
     B = args.batch
     eng.reserve(B)
     # synthetic inputs, resident in HBM; rank r owns global trajectories [r*B, (r+1)*B)
@@ -125,7 +126,7 @@ def main():
         rec = {
             "metric": "integration-steps/sec (whole node)", "value": value, "unit": "trajectory-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via split-fp16 MFMA (hi + 2^-11 lo, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "mdqm9 ambient sampler: 65536 molecules/GPU x 18 atoms (fully connected, 306 edges), cPaiNN F=128 L=5, "
                                    "Euler-Maruyama steps of the 1000-step grid, T1 over a 6-rung ladder",
                        "trajectories_per_gpu": B, "atoms": A, "n_features": F, "score_layers": L, "scheme": "em", "eps": args.eps,

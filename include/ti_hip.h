@@ -51,6 +51,7 @@ extern "C" {
 enum { TI_OK = 0, TI_E_ARG = -1, TI_E_HIP = -2, TI_E_NAN = -3, TI_E_ALLOC = -4, TI_E_UNSUPPORTED = -5 };
 enum { TI_MEM_HOST = 0, TI_MEM_DEVICE = 1 };
 enum { TI_VARIANT_AMBIENT = 0, TI_VARIANT_LATENT_MULTI = 1, TI_VARIANT_LATENT_SINGLE = 2 };
+enum { TI_PREC_F32 = 0, TI_PREC_F16X2 = 1 };
 /* Fixed-step schemes on a caller-supplied grid t[0..n_step-1] (the reference passes torch.linspace(start,end,n_step),
  * integrators.py:43; reversed grid for reverse_ode).  Build-defined (SURVEY.md F3 / §8a row I-new):
  *   EULER: x_{k+1} = x_k + dt_k b(x_k,t_k)                  (== torchdiffeq method='euler' on that grid)
@@ -73,6 +74,9 @@ typedef struct ti_painn_desc {
     float   length_scale;   /* ... for edge distances (reference: 10) */
     float   temp_mean;      /* mean(temperatures)            (embedding.py:209) */
     float   temp_range;     /* max(temperatures) - min(...)  (embedding.py:210) */
+    int32_t precision;      /* TI_PREC_F32: f32 MFMA (default); TI_PREC_F16X2: the message MLPs' matrix products on the fp16
+                               matrix rate with every fp32 operand split into two fp16 halves (hi + 2^-11 lo, all four
+                               cross products, fp32 accumulation; ~22 significand bits, operands must be < 65504) */
 } ti_painn_desc;
 
 typedef struct ti_adw_desc {

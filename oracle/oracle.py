@@ -20,7 +20,7 @@ _SRCS = [os.path.join(HERE, f) for f in ("ti_oracle.c", "ti_oracle_impl.h", "Mak
 class PainnDesc(C.Structure):
     _fields_ = [("variant", C.c_int32), ("n_features", C.c_int32), ("n_layers", C.c_int32), ("n_types", C.c_int32),
                 ("n_atoms", C.c_int32), ("n_edges", C.c_int32), ("temp_length", C.c_float), ("time_length", C.c_float),
-                ("length_scale", C.c_float), ("temp_mean", C.c_float), ("temp_range", C.c_float)]
+                ("length_scale", C.c_float), ("temp_mean", C.c_float), ("temp_range", C.c_float), ("precision", C.c_int32)]
 
 
 class AdwDesc(C.Structure):
@@ -87,7 +87,7 @@ class PainnOracle:
                  temp_length=100.0, time_length=10.0, length_scale=10.0, temperatures=(300, 400, 500, 600, 700, 800, 900, 1000)):
         temps = np.asarray(temperatures, np.float32)
         self.desc = PainnDesc(variant, F, L, n_types, A, len(edge_src), temp_length, time_length, length_scale,
-                              float(temps.mean(dtype=np.float32)), float(temps.max() - temps.min()))
+                              float(temps.mean(dtype=np.float32)), float(temps.max() - temps.min()), 0)
         self.A, self.F, self.E, self.variant = A, F, len(edge_src), variant
         self.ncond = {0: 2, 1: 1, 2: 0}[variant]
         w = f32(flat_weights)

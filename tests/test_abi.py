@@ -56,7 +56,7 @@ def test_no_cpu_fallback_without_gpu(lib):
 def test_create_argument_validation(lib):
     """Checks that run before the device is touched return TI_E_ARG / TI_E_UNSUPPORTED with a message."""
     ti = pkg()
-    d = ti._lib.PainnDesc(0, 48, 2, 25, 3, 6, 100.0, 10.0, 10.0, 650.0, 700.0)       # F = 48 is not supported
+    d = ti._lib.PainnDesc(0, 48, 2, 25, 3, 6, 100.0, 10.0, 10.0, 650.0, 700.0, 0)    # F = 48 is not supported
     w = np.zeros(4, np.float32)
     z = np.zeros(6, np.int32)
     h = lib.ti_painn_create(C.byref(d), ti._lib.fptr(w), 4, ti._lib.iptr(z), ti._lib.iptr(z), ti._lib.iptr(z), ti._lib.iptr(z), 0)

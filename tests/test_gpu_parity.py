@@ -216,3 +216,21 @@ def test_device_resident_buffers_match_host_path():
     assert dev.is_cuda
     np.testing.assert_array_equal(dev.cpu().numpy(), host)
     np.testing.assert_array_equal(eng.drift(xd, 0.25, cd).cpu().numpy(), eng.drift(g["x"], 0.25, g["cond"]))
+
+
+# ------------------------------------------------------------------------------------------------- split-fp16 mode
+@pytest.mark.parametrize("name", PAINN_CASES)
+def test_split_fp16_precision_mode_meets_the_same_bar(name):
+    """precision='f16x2': the message MLPs' products on the fp16 matrix rate, operands split hi + 2^-11 lo.  Same bar
+    as the f32-MFMA path against the reference goldens; the measured error is reported for DESIGN.md."""
+    g = load_golden(name)
+    ti = pkg()
+    eng = ti.engine.PainnEngine(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                                g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"],
+                                precision="f16x2")
+    ref32 = engine_from_golden(g)
+    for i, t in enumerate(g["ts"]):
+        got = eng.drift(g["x"], float(t), g["cond"])
+        err, err32 = rel_l2(got, g[f"drift_{i}"]), rel_l2(ref32.drift(g["x"], float(t), g["cond"]), g[f"drift_{i}"])
+        print(f"\n[split-fp16] {name} t={float(t):.2f}: rel-L2 vs reference {err:.2e} (f32-MFMA path {err32:.2e})")
+        assert np.isfinite(got).all() and err < DRIFT_TOL, (name, i, err)

@@ -16,6 +16,7 @@ SO_PATH = os.path.join(HERE, "libti_hip.so")
 TI_OK, TI_E_ARG, TI_E_HIP, TI_E_NAN, TI_E_ALLOC, TI_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 SCHEMES = {"euler": 0, "heun": 1, "em": 2}
+PRECISIONS = {"f32": 0, "f16x2": 1}
 KERNELS = {"painn_edge": 0, "painn_update": 1, "painn_embed": 2, "painn_readout": 3, "adw": 4, "integrate": 5}
 
 # every symbol include/ti_hip.h declares (tests/test_abi.py checks the library exports exactly these)
@@ -31,7 +32,7 @@ ABI_SYMBOLS = [
 class PainnDesc(C.Structure):
     _fields_ = [("variant", C.c_int32), ("n_features", C.c_int32), ("n_layers", C.c_int32), ("n_types", C.c_int32),
                 ("n_atoms", C.c_int32), ("n_edges", C.c_int32), ("temp_length", C.c_float), ("time_length", C.c_float),
-                ("length_scale", C.c_float), ("temp_mean", C.c_float), ("temp_range", C.c_float)]
+                ("length_scale", C.c_float), ("temp_mean", C.c_float), ("temp_range", C.c_float), ("precision", C.c_int32)]
 
 
 class AdwDesc(C.Structure):

@@ -421,6 +421,86 @@ __device__ __forceinline__ void posenc_set(Act<NBK>& a, float x_over_len, int q)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-fp16 operands for the fp16 matrix rate (16x the f32 MFMA rate) at fp32-like accuracy.
+//   x = xh + 2^-11 * xl,   xh = fp16(x),  xl = fp16((x - xh) * 2^11)          (22 significand bits; |x| < 65504)
+//   x*w = xh*wh + 2^-11 (xh*wl + xl*wh) + 2^-22 xl*wl                          (all four products, fp32 accumulation)
+// on v_mfma_f32_16x16x32_f16.  One instruction covers a PAIR of 16-feature blocks (k = 32): lane (j, q) supplies the 8
+// k-slots (q, i): i < 4 -> feature 16*(2m) + 4q + i, i >= 4 -> feature 16*(2m+1) + 4q + (i-4), i.e. exactly the 8 values
+// it already holds in registers b[2m], b[2m+1] -- the chaining property of the fp32 layout is kept.  Weights are split
+// on the host (pack_chunk16_split) with the same k-slot order; a chunk is still 16 KB at F = 128.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma16h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+template <int NBK, bool SPLIT>
+struct Opnd {                                   // fp32 operand: the activation set itself
+    Act<NBK> a;
+    __device__ __forceinline__ void set(const Act<NBK>& x) { a = x; }
+};
+template <int NBK>
+struct Opnd<NBK, true> {                        // split operand: hi and scaled-lo halves, NBK/2 k-steps
+    h8 hi[NBK / 2], lo[NBK / 2];
+    __device__ __forceinline__ void set(const Act<NBK>& x)
+    {
+#pragma unroll
+        for (int m = 0; m < NBK / 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = i < 4 ? x.b[2 * m][i] : x.b[2 * m + 1][i - 4];
+                const _Float16 h = (_Float16)v;
+                hi[m][i] = h;
+                lo[m][i] = (_Float16)((v - (float)h) * 2048.0f);
+            }
+    }
+};
+
+// chunk image: [(blk*(NBK/2) + m)*2 + {0: hi, 1: lo}][lane] of 16-byte h8.  One output block at a time keeps only three
+// accumulators and two weight fragments live (the matrix pipe is no longer the bottleneck in this mode).
+template <int NBK, bool FLIP>
+__device__ __forceinline__ void gemm_split_block(f32x4& acc, const Opnd<NBK, true>& in, const h8* wl, int lane)
+{
+    constexpr int KS = NBK / 2;
+    f32x4 x = {0, 0, 0, 0}, l = {0, 0, 0, 0};
+    h8 wh = wl[lane], wlo = wl[64 + lane];
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+        // fragment of the next k-step is read ahead; the compiler barrier keeps hipcc from hoisting ALL reads (64 VGPRs)
+        const int nx = m + 1 < KS ? m + 1 : m;
+        const h8 nh = wl[(nx * 2 + 0) * 64 + lane], nl = wl[(nx * 2 + 1) * 64 + lane];
+        asm volatile("" ::: "memory");
+        if (FLIP) {
+            acc = mfma16h(in.hi[m], wh, acc); x = mfma16h(in.lo[m], wh, x);
+            l = mfma16h(in.lo[m], wlo, l);    x = mfma16h(in.hi[m], wlo, x);
+        } else {
+            acc = mfma16h(wh, in.hi[m], acc); x = mfma16h(wh, in.lo[m], x);
+            l = mfma16h(wlo, in.lo[m], l);    x = mfma16h(wlo, in.hi[m], x);
+        }
+        wh = nh; wlo = nl;
+    }
+    acc += x * 4.8828125e-4f + l * 2.384185791015625e-7f;               // 2^-11, 2^-22
+}
+template <int NBK>
+__device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd<NBK, true>& in, const f32x4* wl4, int lane)
+{
+    const h8* wl = reinterpret_cast<const h8*>(wl4);
+    gemm_split_block<NBK, false>(acc0, in, wl, lane);
+    gemm_split_block<NBK, false>(acc1, in, wl + NBK * 64, lane);
+}
+template <int NBK>
+__device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK, true>& in, const f32x4* wl4, int lane)
+{
+    const h8* wl = reinterpret_cast<const h8*>(wl4);
+    gemm_split_block<NBK, true>(acc0, in, wl, lane);
+    gemm_split_block<NBK, true>(acc1, in, wl + NBK * 64, lane);
+}
+// fp32 operands through the same interface
+template <int NBK>
+__device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd<NBK, false>& in, const f32x4* wl, int lane) { gemm_bt(acc0, acc1, in.a, wl, lane); }
+template <int NBK>
+__device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK, false>& in, const f32x4* wl, int lane) { gemm_fl(acc0, acc1, in.a, wl, lane); }
+
 }  // namespace r16
 
 }  // namespace ti

@@ -114,14 +114,16 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 // One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
 // 4 waves per workgroup share the weight-chunk stream; 2 workgroups per CU (F <= 128) run out of phase and hide each
 // other's LayerNorm / reduction / wait phases behind matrix work.
+// SPLIT selects the split-fp16 matrix path (mfma_chain.hpp: Opnd<NBK, true>) instead of the f32 MFMA.
 #ifndef TI_EDGE_OCC
 #define TI_EDGE_OCC 2
 #endif
-template <int NBK, bool FIRST, bool LAST>
+template <int NBK, bool FIRST, bool LAST, bool SPLIT>
 __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_kernel(const EdgeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
     float* scratch = reinterpret_cast<float*>(lds + 4 * CH4) + wave * 64;          // [16 rows][4] edge_dir of the block
@@ -155,57 +157,68 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
             }
         }
         // ---- w(enc(d)) hidden layers
-        A16 g2;
+        OP g2;
         {
-            A16 g1;
+            OP g1;
+            A16 t1;
             {
-                A16 enc;
-                r16::posenc_set(enc, dist / p.length_scale, q);
+                OP enc;
+                {
+                    A16 t;
+                    r16::posenc_set(t, dist / p.length_scale, q);
+                    enc.set(t);
+                }
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const f32x4* wl = pipe.acquire();
                     f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
                     r16::gemm_bt(a0, a1, enc, wl, lane);
-                    g1.b[2 * c] = a0; g1.b[2 * c + 1] = a1;
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                     pipe.release();
                 }
             }
-            r16::ln_silu(g1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
+            r16::ln_silu(t1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
+            g1.set(t1);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
                 r16::gemm_bt(a0, a1, g1, wl, lane);
-                g2.b[2 * c] = a0; g2.b[2 * c + 1] = a1;
+                t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
-            r16::ln_silu(g2, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
+            r16::ln_silu(t1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
+            g2.set(t1);
         }
         // ---- phi([s[src] | e]) hidden layers; the s[src] half of the first Linear is P[src] (node kernels)
-        A16 h2;
+        OP h2;
         {
-            A16 h1, ein;
-            if (FIRST) r16::load_set(ein, p.edge_emb + row_type(meta) * F, q);
-            else       r16::load_set(ein, p.e + (erow0 + j) * F, q);
+            OP h1, ein;
+            A16 t1;
+            if (FIRST) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
+            else       r16::load_set(t1, p.e + (erow0 + j) * F, q);
+            ein.set(t1);
             const float* prow = p.P + (size_t)nsrc * F;
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
                 r16::gemm_bt(a0, a1, ein, wl, lane);
-                h1.b[2 * c] = a0; h1.b[2 * c + 1] = a1;
+                t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
-            r16::ln_silu(h1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
+            r16::ln_silu(t1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
+            h1.set(t1);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
                 r16::gemm_bt(a0, a1, h1, wl, lane);
-                h2.b[2 * c] = a0; h2.b[2 * c + 1] = a1;
+                t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
-            r16::ln_silu(h2, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
+            r16::ln_silu(t1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
+            h2.set(t1);
         }
         // ---- output layer, flipped: features on lanes (l & 15), the block's rows 4q + r in registers
         uint32_t mi[4];
@@ -537,10 +550,14 @@ static hipError_t configure_nb()
 #define TI_SET(k) if ((e = set_lds(k, b)) != hipSuccess) return e
     TI_SET((painn_embed_kernel<NB, WAVES, 2>)); TI_SET((painn_embed_kernel<NB, WAVES, 3>)); TI_SET((painn_embed_kernel<NB, WAVES, 4>));
     const size_t be = edge_lds_bytes(NB);
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, false>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, false>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, false>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, false>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, true>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, true>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, true>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, true>, be)) != hipSuccess) return e;
     TI_SET((painn_update_kernel<NB, WAVES, true>)); TI_SET((painn_update_kernel<NB, WAVES, false>));
     TI_SET((painn_readout_kernel<NB, WAVES>));
 #undef TI_SET
@@ -584,16 +601,23 @@ hipError_t launch_embed(int NBv, int nseg, const EmbedParams& p, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_edge(int NBv, bool first, bool last, const EdgeParams& p, hipStream_t st)
+hipError_t launch_edge(int NBv, bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
         (void)WAVES;
         const dim3 g((unsigned)((p.n_groups + 3) / 4));          // 4 waves (= 4 molecule groups) per workgroup
         const size_t l = edge_lds_bytes(NB);
-        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true>), g, dim3(256), l, st, p);
-        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false>), g, dim3(256), l, st, p);
-        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true>), g, dim3(256), l, st, p);
-        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false>), g, dim3(256), l, st, p);
+        if (split) {
+            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true>), g, dim3(256), l, st, p);
+            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true>), g, dim3(256), l, st, p);
+            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true>), g, dim3(256), l, st, p);
+        } else {
+            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false>), g, dim3(256), l, st, p);
+            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false>), g, dim3(256), l, st, p);
+            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false>), g, dim3(256), l, st, p);
+        }
     });
     return hipGetLastError();
 }

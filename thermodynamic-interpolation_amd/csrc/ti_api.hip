@@ -50,6 +50,28 @@ void pack_chunk16(std::vector<float>& dst, const float* W, int ld, int n_rows, i
                 }
 }
 
+// split-fp16 chunk of the edge kernel (mfma_chain.hpp, r16::Opnd<NBK,true>): 16-byte h8 fragments
+//   frag[((blk*(NBK/2) + m)*2 + {0 hi, 1 lo})*64 + l][i] = half of W[row0 + 16*blk + (l&15)][col0 + 16*(2m + (i>>2)) + 4*(l>>4) + (i&3)]
+// with hi = fp16(w), lo = fp16((w - hi) * 2^11).  Same byte size as the fp32 chunk.
+void pack_chunk16_split(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBK)
+{
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)2 * NBK * 64 * 4);
+    _Float16* out = reinterpret_cast<_Float16*>(dst.data() + base);
+    const int KS = NBK / 2;
+    for (int blk = 0; blk < 2; ++blk)
+        for (int m = 0; m < KS; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 8; ++i) {
+                    const int row = row0 + 16 * blk + (l & 15), col = col0 + 16 * (2 * m + (i >> 2)) + 4 * (l >> 4) + (i & 3);
+                    const float w = row < n_rows ? W[(size_t)row * ld + col] : 0.f;
+                    const _Float16 h = (_Float16)w;
+                    const _Float16 lo = (_Float16)((w - (float)h) * 2048.0f);
+                    out[((size_t)((blk * KS + m) * 2 + 0) * 64 + l) * 8 + i] = h;
+                    out[((size_t)((blk * KS + m) * 2 + 1) * 64 + l) * 8 + i] = lo;
+                }
+}
+
 struct MlpOff { size_t W0, b0, g0, be0, W1, b1, g1, be1, W2, b2; int f_in, f_h, f_out; };
 static size_t take_mlp(MlpOff& m, size_t o, int f_in, int f_h, int f_out)
 {
@@ -196,7 +218,11 @@ void pack_painn(ti_handle* h, const float* wts)
         const bool first = l == 0, last = l == L - 1;
         o = begin_stream();                          // edge kernel: 16-row chunk format
         const int NBK = F / 16;
-        auto layer16 = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) pack_chunk16(pk, wts + W, ld, n_rows, 32 * nbo, col0, NBK); };
+        const bool split = h->d.precision == TI_PREC_F16X2;
+        auto chunk16 = [&](size_t W, int ld, int n_rows, int row0, int col0) {
+            if (split) pack_chunk16_split(pk, wts + W, ld, n_rows, row0, col0, NBK); else pack_chunk16(pk, wts + W, ld, n_rows, row0, col0, NBK);
+        };
+        auto layer16 = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) chunk16(W, ld, n_rows, 32 * nbo, col0); };
         layer16(h->w[l].W0, F, F, 0); layer16(h->w[l].W1, F, F, 0);
         layer16(h->phi[l].W0, 2 * F, F, F);        // the e half of [s[src] | e]
         layer16(h->phi[l].W1, F, F, 0);
@@ -204,8 +230,8 @@ void pack_painn(ti_handle* h, const float* wts)
             for (int c : {2, 3, 1, 0, 4}) {       // consumption order of painn_edge_kernel: ds, de, sed, gates, cross gates
                 if (c == 3 && last) continue;
                 if ((c == 0 || c == 4) && first) continue;
-                pack_chunk16(pk, wts + h->phi[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NBK);
-                pack_chunk16(pk, wts + h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NBK);
+                chunk16(h->phi[l].W2, F, 5 * F, c * F + 32 * nbo, 0);
+                chunk16(h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0);
             }
         h->st_edge.push_back(end_stream(o));
         o = begin_stream();
@@ -280,7 +306,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             p.nblk = h->nblk; p.G = h->G; p.A = A; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
             p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
-            HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, p, st));
+            HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, h->d.precision == TI_PREC_F16X2, p, st));
         }
         if (h->tap == 1 + 2 * l) return;
         {
@@ -459,6 +485,7 @@ ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t 
         if (E < 0 || (E > 0 && (!edge_src || !edge_dst || !edge_type))) return fail(TI_E_ARG, "edge arrays missing");
         if (d->variant < 0 || d->variant > 2) return fail(TI_E_ARG, "unknown variant");
         if (d->n_types < 1) return fail(TI_E_ARG, "n_types must be >= 1");
+        if (d->precision != TI_PREC_F32 && d->precision != TI_PREC_F16X2) return fail(TI_E_ARG, "unknown precision");
         for (int k = 0; k < E; ++k)
             if (edge_src[k] < 0 || edge_src[k] >= A || edge_dst[k] < 0 || edge_dst[k] >= A || edge_type[k] < 0 || edge_type[k] > 3)
                 return fail(TI_E_ARG, "edge index / type out of range");

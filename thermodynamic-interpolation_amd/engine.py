@@ -90,7 +90,10 @@ class PainnEngine(_Engine):
     """cPaiNN drift + fixed-step integrator for one molecular species (homogeneous batches)."""
 
     def __init__(self, variant, F, L, A, edge_src, edge_dst, edge_type, atom_ids, flat_weights, *, n_types=25, temp_length=10.0,
-                 time_length=10.0, length_scale=10.0, temperatures=(300, 400, 500, 600, 700, 800, 900, 1000), device=0):
+                 time_length=10.0, length_scale=10.0, temperatures=(300, 400, 500, 600, 700, 800, 900, 1000), device=0, precision="f32"):
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        self.precision = precision
         temps = np.asarray(temperatures, np.float32)
         es, ed, et, ai = (np.ascontiguousarray(a, np.int32) for a in (edge_src, edge_dst, edge_type, atom_ids))
         if not (es.shape == ed.shape == et.shape) or es.ndim != 1 or ai.shape != (A,):
@@ -98,7 +101,7 @@ class PainnEngine(_Engine):
         self.variant, self.F, self.L, self.A, self.E = int(variant), int(F), int(L), int(A), int(es.size)
         self.ncond = W.N_COND[self.variant]
         self.desc = _lib.PainnDesc(self.variant, self.F, self.L, int(n_types), self.A, self.E, float(temp_length), float(time_length),
-                                   float(length_scale), float(temps.mean(dtype=np.float32)), float(temps.max() - temps.min()))
+                                   float(length_scale), float(temps.mean(dtype=np.float32)), float(temps.max() - temps.min()), _lib.PRECISIONS[precision])
         w = np.ascontiguousarray(flat_weights, np.float32)
         self.device = int(device)
         self.h = _lib.lib().ti_painn_create(C.byref(self.desc), _lib.fptr(w), w.size, _lib.iptr(es), _lib.iptr(ed), _lib.iptr(et),
