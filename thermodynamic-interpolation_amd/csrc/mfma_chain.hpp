@@ -146,8 +146,10 @@ struct PipeDMA {
             dma(g + (size_t)next * SUP4, base + (par ^ 1) * SUP4);
         }
         if (++sub == SC) {
+#ifndef TI_ABL_NOBARRIER         // ablation build (timing only, racy): no drain, no workgroup barrier at the superchunk boundary
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#endif
             idx = (idx + 1 == nsup) ? 0 : idx + 1;
             par ^= 1; sub = 0;
         }

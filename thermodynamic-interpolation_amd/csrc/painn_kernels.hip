@@ -298,7 +298,11 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
                         m2 = m2 < p.B ? m2 : p.B - 1;
                         const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
 #pragma unroll
+#ifdef TI_ABL_NOGATHER          // ablation build (timing only, wrong results): no v[src] gather
+                        for (int c = 0; c < 3; ++c) { vs[c][0][r] = 0.5f; vs[c][1][r] = 0.25f; (void)vp; }
+#else
                         for (int c = 0; c < 3; ++c) { vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16]; }
+#endif
                     }
                     out_pair(0, nbo, gt0, gt1);
                 }
@@ -333,18 +337,28 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
 
 // ================================================================================================== update kernel
 // v <- v + dv  with  dv = dvacc + cacc x v   (the cross product with v[dst] factors out of the edge sum),
-// then Update.forward; finally P for the next layer's message block.
-template <int NB, int WAVES, bool HAS_NEXT>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_update_kernel(const UpdateParams p)
-{
-    using C = Cfg<NB, WAVES>;
-    constexpr int F = C::F;
-    extern __shared__ f32x4 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5;
-    Pipe<NB, C::T> pipe;
-    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);
+// s <- s + dsacc, then Update.forward (cpainn.py:345-376); finally P for the next layer's message block.
+// 16 atoms per wave on the r16 primitives (f32 or split-fp16 matrix path), 4 waves per workgroup, 2 workgroups per CU.
+// The three spatial components share every visit of the U / V weight chunks.
+struct UV {                                         // per-layer vector block in LDS, x F floats
+    static constexpr int B0 = 0, G0 = 1, BE0 = 2, B1 = 3, G1 = 4, BE1 = 5, B2 = 6 /* 3F: gates | scale | add */, PB0 = 9, COUNT = 10;
+};
 
-    const long long node = ((long long)blockIdx.x * WAVES + wave) * 32 + j;
+template <int NBK, bool HAS_NEXT, bool SPLIT>
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(const UpdateParams p)
+{
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    float* vec = reinterpret_cast<float*>(lds + 4 * CH4);                          // [UV::COUNT][F]
+    for (int i = threadIdx.x; i < UV::COUNT * F / 4; i += T)
+        reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
+    PipeDMA<NB, T, 2> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+
+    const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
     const bool ok = node < p.N;
     const size_t nd = (size_t)(ok ? node : p.N - 1);
     float* vb = p.v + nd * 3 * F;
@@ -354,132 +368,169 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_update_kernel(con
     float* ab = p.dsacc + nd * F;                 // sum of the invariant messages of this layer (edge kernel)
 
     // ---- phase A: v_eff = v + dvacc + cacc x v (parked in dvacc), n2 = |V v_eff|^2 over the 3 components
-    Act<NB> n2;
+    A16 n2;
+    {
+        OP ve[3];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) n2.b[nb] = f32x16{0};
+        for (int c = 0; c < 3; ++c) {
+            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+            A16 t;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-        Act<NB> ve;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f32x16 vc = load_block(vb + c * F, nb, h), dd = load_block(db + c * F, nb, h);
-            const f32x16 v1 = load_block(vb + c1 * F, nb, h), v2 = load_block(vb + c2 * F, nb, h);
-            const f32x16 k1 = load_block(cb + c1 * F, nb, h), k2 = load_block(cb + c2 * F, nb, h);
-            ve.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);              // torch.cross(edge_dir, v[dst]) summed over edges
-            if (ok) store_block(db + c * F, nb, h, ve.b[nb]);
+            for (int nb = 0; nb < NBK; ++nb) {
+                const f32x4 vc = r16::load_block(vb + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
+                const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
+                const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
+                t.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);              // torch.cross(edge_dir, v[dst]) summed over edges
+                if (ok) r16::store_block(db + c * F, nb, q, t.b[nb]);
+            }
+            ve[c].set(t);
         }
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) {
-            const f32x4* wl = pipe.begin();
-            f32x16 a = {0};
-            gemm_bt(a, ve, wl, lane);                                 // vv = V v
-            pipe.end();
-            n2.b[nbo] += a * a;
+        for (int nb = 0; nb < NBK; ++nb) n2.b[nb] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+                r16::gemm_bt(a0, a1, ve[c], wl, lane);                   // vv = V v
+                n2.b[2 * ch] += a0 * a0; n2.b[2 * ch + 1] += a1 * a1;
+            }
+            pipe.release();
         }
     }
     // ---- phase B: MLP([ |vv| , s ])
-    Act<NB> h2;
+    OP h2;
     {
-        Act<NB> acc;
+        A16 t;
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) acc.b[nbo] = load_block(p.mlp.b0, nbo, h);
+        for (int nb = 0; nb < NBK; ++nb) t.b[nb] = r16::load_block(vec + UV::B0 * F, nb, q);
         {
-            Act<NB> nn;
+            OP nn;
+            {
+                A16 u;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) nn.b[nb][i] = sqrtf(n2.b[nb][i]);
+                    for (int r = 0; r < 4; ++r) u.b[nb][r] = sqrtf(n2.b[nb][r]);
+                nn.set(u);
+            }
 #pragma unroll
-            for (int nbo = 0; nbo < NB; ++nbo) {
-                const f32x4* wl = pipe.begin();
-                gemm_bt(acc.b[nbo], nn, wl, lane);
-                pipe.end();
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], nn, wl, lane);
+                pipe.release();
             }
         }
         {
-            Act<NB> ss;
+            OP ss;
+            {
+                A16 u;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) ss.b[nb] = load_block(sb, nb, h) + load_block(ab, nb, h);      // s += ds
+                for (int nb = 0; nb < NBK; ++nb) u.b[nb] = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);      // s += ds
+                ss.set(u);
+            }
 #pragma unroll
-            for (int nbo = 0; nbo < NB; ++nbo) {
-                const f32x4* wl = pipe.begin();
-                gemm_bt(acc.b[nbo], ss, wl, lane);
-                pipe.end();
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], ss, wl, lane);
+                pipe.release();
             }
         }
-        ln_silu(acc, p.mlp.g0, p.mlp.be0, h);
+        r16::ln_silu(t, vec + UV::G0 * F, vec + UV::BE0 * F, q);
+        OP h1;
+        h1.set(t);
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) {
-            const f32x4* wl = pipe.begin();
-            f32x16 a = load_block(p.mlp.b1, nbo, h);
-            gemm_bt(a, acc, wl, lane);
-            h2.b[nbo] = a;
-            pipe.end();
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(vec + UV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B1 * F, 2 * ch + 1, q);
+            r16::gemm_bt(a0, a1, h1, wl, lane);
+            t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1;
+            pipe.release();
         }
-        ln_silu(h2, p.mlp.g1, p.mlp.be1, h);
+        r16::ln_silu(t, vec + UV::G1 * F, vec + UV::BE1 * F, q);
+        h2.set(t);
     }
-    // output chunks: [scale_squared_norm, add_invariant] per block, then gates
+    // output chunks: [scale_squared_norm, add_invariant] per 32-feature block, then gates
 #pragma unroll
-    for (int nbo = 0; nbo < NB; ++nbo) {
-        const f32x4* wl = pipe.begin();
-        f32x16 q = load_block(p.mlp.b2 + F, nbo, h);
-        gemm_bt(q, h2, wl, lane);
-        pipe.end();
-        wl = pipe.begin();
-        f32x16 a = load_block(p.mlp.b2 + 2 * F, nbo, h);
-        gemm_bt(a, h2, wl, lane);
-        pipe.end();
-        f32x16 so = load_block(sb, nbo, h) + load_block(ab, nbo, h);
+    for (int ch = 0; ch < NB; ++ch) {
+        const f32x4* wl = pipe.acquire();
+        f32x4 q0 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch, q), q1 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch + 1, q);
+        r16::gemm_bt(q0, q1, h2, wl, lane);
+        pipe.release();
+        wl = pipe.acquire();
+        f32x4 a0 = r16::load_block(vec + (UV::B2 + 2) * F, 2 * ch, q), a1 = r16::load_block(vec + (UV::B2 + 2) * F, 2 * ch + 1, q);
+        r16::gemm_bt(a0, a1, h2, wl, lane);
+        pipe.release();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float n = sqrtf(n2.b[nbo][i]);
-            so[i] = so[i] + ((n * n) * q[i] + a[i]);                  // s += vv_norm**2 * scale + add
-        }
-        if (ok) {
-            store_block(sb, nbo, h, so);
-            store_block(ab, nbo, h, f32x16{0});
+        for (int k = 0; k < 2; ++k) {
+            const int nb = 2 * ch + k;
+            f32x4 so = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);
+            const f32x4 qq = k ? q1 : q0, aa = k ? a1 : a0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float n = sqrtf(n2.b[nb][r]);
+                so[r] = so[r] + ((n * n) * qq[r] + aa[r]);              // s += vv_norm**2 * scale + add
+            }
+            if (ok) {
+                r16::store_block(sb, nb, q, so);
+                r16::store_block(ab, nb, q, f32x4{0, 0, 0, 0});
+            }
         }
     }
-    Act<NB> gg;
+    A16 gg;
 #pragma unroll
-    for (int nbo = 0; nbo < NB; ++nbo) {
-        const f32x4* wl = pipe.begin();
-        f32x16 a = load_block(p.mlp.b2, nbo, h);
-        gemm_bt(a, h2, wl, lane);
-        gg.b[nbo] = a;
-        pipe.end();
+    for (int ch = 0; ch < NB; ++ch) {
+        const f32x4* wl = pipe.acquire();
+        f32x4 a0 = r16::load_block(vec + UV::B2 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B2 * F, 2 * ch + 1, q);
+        r16::gemm_bt(a0, a1, h2, wl, lane);
+        gg.b[2 * ch] = a0; gg.b[2 * ch + 1] = a1;
+        pipe.release();
     }
     // ---- phase C: v = v_eff + (U v_eff) * gates ; reset the accumulators for the next layer
+    {
+        OP ve[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        Act<NB> ve;
-        load_set(ve, db + c * F, h);
+        for (int c = 0; c < 3; ++c) {
+            A16 t;
+            r16::load_set(t, db + c * F, q);
+            ve[c].set(t);
+        }
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) {
-            const f32x4* wl = pipe.begin();
-            f32x16 a = {0};
-            gemm_bt(a, ve, wl, lane);
-            pipe.end();
-            const f32x16 vn = ve.b[nbo] + a * gg.b[nbo];
-            if (ok) {
-                store_block(vb + c * F, nbo, h, vn);
-                store_block(db + c * F, nbo, h, f32x16{0});
-                store_block(cb + c * F, nbo, h, f32x16{0});
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+                r16::gemm_bt(a0, a1, ve[c], wl, lane);
+                const f32x4 e0 = r16::load_block(db + c * F, 2 * ch, q), e1 = r16::load_block(db + c * F, 2 * ch + 1, q);
+                if (ok) {
+                    r16::store_block(vb + c * F, 2 * ch, q, e0 + a0 * gg.b[2 * ch]);
+                    r16::store_block(vb + c * F, 2 * ch + 1, q, e1 + a1 * gg.b[2 * ch + 1]);
+                    r16::store_block(db + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
+                    r16::store_block(db + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
+                    r16::store_block(cb + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
+                    r16::store_block(cb + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
+                }
             }
+            pipe.release();
         }
     }
     // ---- phase D: P for the next message block
     if (HAS_NEXT) {
-        Act<NB> sn;
-        load_set(sn, sb, h);
+        OP sn;
+        {
+            A16 t;
+            r16::load_set(t, sb, q);
+            sn.set(t);
+        }
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) {
-            const f32x4* wl = pipe.begin();
-            f32x16 a = load_block(p.pb0_next, nbo, h);
-            gemm_bt(a, sn, wl, lane);
-            pipe.end();
-            if (ok) store_block(p.P + nd * F, nbo, h, a);
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(vec + UV::PB0 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::PB0 * F, 2 * ch + 1, q);
+            r16::gemm_bt(a0, a1, sn, wl, lane);
+            pipe.release();
+            if (ok) { r16::store_block(p.P + nd * F, 2 * ch, q, a0); r16::store_block(p.P + nd * F, 2 * ch + 1, q, a1); }
         }
     }
 }
@@ -542,6 +593,8 @@ static hipError_t set_lds(K kernel, size_t bytes)
 // edge kernel LDS: two superchunks of two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors
 static size_t edge_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 4 * 256 + 21 * (size_t)32 * NB * 4; }
 
+static size_t update_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 10 * (size_t)32 * NB * 4; }
+
 template <int NB, int WAVES>
 static hipError_t configure_nb()
 {
@@ -558,7 +611,11 @@ static hipError_t configure_nb()
     if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, true>, be)) != hipSuccess) return e;
     if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, true>, be)) != hipSuccess) return e;
     if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, true>, be)) != hipSuccess) return e;
-    TI_SET((painn_update_kernel<NB, WAVES, true>)); TI_SET((painn_update_kernel<NB, WAVES, false>));
+    const size_t bu = update_lds_bytes(NB);
+    if ((e = set_lds(painn_update_kernel<2 * NB, true, false>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, false, false>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, true, true>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, false, true>, bu)) != hipSuccess) return e;
     TI_SET((painn_readout_kernel<NB, WAVES>));
 #undef TI_SET
     return hipSuccess;
@@ -622,13 +679,19 @@ hipError_t launch_edge(int NBv, bool first, bool last, bool split, const EdgePar
     return hipGetLastError();
 }
 
-hipError_t launch_update(int NBv, bool has_next, const UpdateParams& p, hipStream_t st)
+hipError_t launch_update(int NBv, bool has_next, bool split, const UpdateParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
-        const dim3 g = node_grid<NB, WAVES>(p.N);
-        const size_t l = Cfg<NB, WAVES>::lds_bytes;
-        if (has_next) hipLaunchKernelGGL((painn_update_kernel<NB, WAVES, true>), g, dim3(64 * WAVES), l, st, p);
-        else hipLaunchKernelGGL((painn_update_kernel<NB, WAVES, false>), g, dim3(64 * WAVES), l, st, p);
+        (void)WAVES;
+        const dim3 g((unsigned)((p.N + 63) / 64));                 // 4 waves x 16 atoms per workgroup
+        const size_t l = update_lds_bytes(NB);
+        if (split) {
+            if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, true>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, true>), g, dim3(256), l, st, p);
+        } else {
+            if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, false>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, false>), g, dim3(256), l, st, p);
+        }
     });
     return hipGetLastError();
 }

@@ -118,7 +118,7 @@ struct ti_handle {
     Stream st_embed{}, st_readout{}; std::vector<Stream> st_edge, st_update;
     DevBuf<uint32_t> rows; DevBuf<int32_t> slotnode, nslots, atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
-    DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs;
+    DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs, upd_vecs;
     int tap = -1; long long last_B = 0;
 
     // ---- adw
@@ -234,17 +234,18 @@ void pack_painn(ti_handle* h, const float* wts)
                 chunk16(h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0);
             }
         h->st_edge.push_back(end_stream(o));
-        o = begin_stream();
-        for (int c = 0; c < 3; ++c) layer(h->V[l], F, F, 0);
-        layer(h->upd[l].W0, 2 * F, F, 0); layer(h->upd[l].W0, 2 * F, F, F);
-        layer(h->upd[l].W1, F, F, 0);
+        o = begin_stream();                          // update kernel: 16-row chunk format, order of painn_update_kernel
+        layer16(h->V[l], F, F, 0);                                                    // phase A (3 components per visit)
+        layer16(h->upd[l].W0, 2 * F, F, 0); layer16(h->upd[l].W0, 2 * F, F, F);      // MLP L1: |vv| part, s part
+        layer16(h->upd[l].W1, F, F, 0);
         for (int nbo = 0; nbo < NB; ++nbo) {
-            pack_chunk(pk, wts + h->upd[l].W2, F, 3 * F, F + 32 * nbo, 0, NB);       // scale_squared_norm
-            pack_chunk(pk, wts + h->upd[l].W2, F, 3 * F, 2 * F + 32 * nbo, 0, NB);   // add_invariant_features
+            chunk16(h->upd[l].W2, F, 3 * F, F + 32 * nbo, 0);                         // scale_squared_norm
+            chunk16(h->upd[l].W2, F, 3 * F, 2 * F + 32 * nbo, 0);                     // add_invariant_features
         }
-        layer(h->upd[l].W2, F, 3 * F, 0);                                             // gates
-        for (int c = 0; c < 3; ++c) layer(h->U[l], F, F, 0);
-        if (!last) layer(h->phi[l + 1].W0, 2 * F, F, 0);
+        layer16(h->upd[l].W2, F, 3 * F, 0);                                           // gates
+        layer16(h->U[l], F, F, 0);                                                    // phase C
+        if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);                            // phase D
+        if (((pk.size() / 4 - o) / (256 * (size_t)NB)) % 2) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f);   // whole superchunks
         h->st_update.push_back(end_stream(o));
     }
     o = begin_stream();
@@ -260,6 +261,15 @@ void pack_painn(ti_handle* h, const float* wts)
         ev.insert(ev.end(), wts + w.b2, wts + w.b2 + 5 * F);
     }
     h->edge_vecs.upload(ev);
+    std::vector<float> uv;                           // order = struct UV in painn_kernels.hip
+    for (int l = 0; l < L; ++l) {
+        const MlpOff& u = h->upd[l];
+        for (size_t off : {u.b0, u.g0, u.be0, u.b1, u.g1, u.be1}) uv.insert(uv.end(), wts + off, wts + off + F);
+        uv.insert(uv.end(), wts + u.b2, wts + u.b2 + 3 * F);
+        if (l + 1 < L) uv.insert(uv.end(), wts + h->phi[l + 1].b0, wts + h->phi[l + 1].b0 + F);
+        else uv.insert(uv.end(), F, 0.f);
+    }
+    h->upd_vecs.upload(uv);
 }
 
 void ensure_painn_ws(ti_handle* h, long long B)
@@ -311,11 +321,10 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         if (h->tap == 1 + 2 * l) return;
         {
             UpdateParams p{};
-            p.stream = h->S(h->st_update[l]); p.nch = h->st_update[l].nch; p.mlp = h->vec(h->upd[l]);
-            p.pb0_next = l + 1 < L ? h->F(h->phi[l + 1].b0) : nullptr;
+            p.stream = h->S(h->st_update[l]); p.nch = h->st_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
             p.N = N; p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.P = h->P.p;
             Timed tm(h, TI_KERNEL_PAINN_UPDATE);
-            HIP_CHECK(launch_update(NB, l + 1 < L, p, st));
+            HIP_CHECK(launch_update(NB, l + 1 < L, h->d.precision == TI_PREC_F16X2, p, st));
         }
         if (h->tap == 2 + 2 * l) return;
     }

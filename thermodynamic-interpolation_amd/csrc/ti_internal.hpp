@@ -56,7 +56,7 @@ struct EmbedParams {
 
 struct UpdateParams {
     const float4* stream; int nch;
-    MlpVec mlp; const float* pb0_next;
+    const float* vecs;                      // [10][F] (painn_kernels.hip: struct UV)
     long long N;
     float *s, *v, *dsacc, *dvacc, *cacc, *P;
 };
@@ -71,7 +71,7 @@ struct ReadoutParams {
 // launchers (painn_kernels.hip).  F = 32*NB; return hipError_t of the launch.
 hipError_t launch_embed(int NB, int nseg, const EmbedParams& p, hipStream_t st);
 hipError_t launch_edge(int NB, bool first, bool last, bool split, const EdgeParams& p, hipStream_t st);
-hipError_t launch_update(int NB, bool has_next, const UpdateParams& p, hipStream_t st);
+hipError_t launch_update(int NB, bool has_next, bool split, const UpdateParams& p, hipStream_t st);
 hipError_t launch_readout(int NB, const ReadoutParams& p, hipStream_t st);
 hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
 
