@@ -75,8 +75,8 @@ typedef struct ti_painn_desc {
     float   temp_mean;      /* mean(temperatures)            (embedding.py:209) */
     float   temp_range;     /* max(temperatures) - min(...)  (embedding.py:210) */
     int32_t precision;      /* TI_PREC_F32: f32 MFMA (default); TI_PREC_F16X2: the message MLPs' matrix products on the fp16
-                               matrix rate with every fp32 operand split into two fp16 halves (hi + 2^-11 lo, all four
-                               cross products, fp32 accumulation; ~22 significand bits, operands must be < 65504) */
+                               matrix rate with every fp32 operand split into two fp16 halves (hi + 2^-11 lo; products
+                               hi*hi, hi*lo, lo*hi; fp32 accumulation; ~24 significand bits, operands must be < 65504) */
 } ti_painn_desc;
 
 typedef struct ti_adw_desc {
