@@ -11,6 +11,11 @@ integrator step of every trajectory of the batch = one drift evaluation + the fu
 independent, so ranks shard them with no data-path collective ("weak" scaling: per-GPU batch fixed); the only
 collective is the final RCCL all-gather of the end states, which is inside the timed region.
 
+Matrix path: `--precision f16x2` (default) runs the message/update MLP products on the fp16 matrix cores with every fp32
+operand split into two fp16 halves (three products, fp32 accumulation); its drift parity against the reference equals the
+f32-MFMA path's (tests/test_gpu_parity.py, profiles/*split_fp16_parity.txt).  `--precision f32` uses v_mfma_f32_16x16x4_f32
+only; by default its throughput is measured in the same run and reported as `f32_mfma_path` next to the headline.
+
 Inputs are resident in HBM before the timed region starts.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,6 +35,7 @@ E_M = A * (A - 1)
 FLOP_PER_MOL_EVAL = F * F * (L * (30 * E_M + 24 * A) + (2 * 4 + 4) * A + 4 * A) + 10 * F * A      # 7.9216e8
 FLOP_PER_EDGE_LAYER = 30 * F * F
 PEAK_F32_MFMA_TFLOPS = 157.3                                                                      # MI355X_MICROARCH.md
+PEAK_F16_MFMA_TFLOPS = 2500.0                                                                     # dense fp16/bf16 MFMA, same guide
 
 
 def parse():
@@ -39,7 +45,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
     ap.add_argument("--eps", type=float, default=0.01)
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x2"], help="matrix path of the message MLPs (DESIGN.md §3.4)")
+    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"], help="matrix path of the message/update MLPs (DESIGN.md §3.4)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the additional f32-MFMA measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512, help="molecules in the CPU-oracle sample")
     return ap.parse_args()
@@ -81,9 +88,7 @@ def main():
     syn, W = ti.synthetic, ti.weights
     template = syn.fully_connected_template(A)
     flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 0), W.painn_param_spec(W.AMBIENT, F, L, 25))
-    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *template, np.arange(A), flat, temp_length=100.0, device=local_rank, precision=args.precision)
     B = args.batch
-    eng.reserve(B)
     # synthetic inputs, resident in HBM; rank r owns global trajectories [r*B, (r+1)*B)
     x0 = torch.from_numpy(syn.molecule_coords(B, A, seed=rank)).to(dev)
     cond = torch.from_numpy(syn.ambient_cond(B, A)).to(dev)
@@ -91,52 +96,75 @@ def main():
     grid = ti.engine.time_grid(0.0, 1.0, 1001)            # config 4: 1000-step grid; we time K of its steps
     gathered = [torch.empty_like(out[0]) for _ in range(world)] if world > 1 else None
 
-    def run(k_steps, first_step):
-        eng.rollout(x0, cond, grid[first_step:first_step + k_steps + 1], scheme="em", eps=args.eps, seed=1234,
-                    traj_offset=rank * B, save_every=0, out=out)
-        if world > 1:
-            dist.all_gather(gathered, out[0])             # the only collective: final gather of the samples (RCCL)
-
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        run(args.warmup, 0)
-    sync()
-    eng.profile(True)
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    sync()
-    elapsed = time.perf_counter() - t0
-    eng.profile(False)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    n_edge, ms_edge = eng.profile_read("painn_edge")
-    n_upd, ms_upd = eng.profile_read("painn_update")
-    assert bool(torch.isfinite(out).all())
+    def measure(precision):
+        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+        eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *template, np.arange(A), flat, temp_length=100.0, device=local_rank,
+                                    precision=precision)
+        eng.reserve(B)
+
+        def run(k_steps, first_step):
+            eng.rollout(x0, cond, grid[first_step:first_step + k_steps + 1], scheme="em", eps=args.eps, seed=1234,
+                        traj_offset=rank * B, save_every=0, out=out)
+            if world > 1:
+                dist.all_gather(gathered, out[0])         # the only collective: final gather of the samples (RCCL)
+
+        if args.warmup > 0:
+            run(args.warmup, 0)
+        sync()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        run(args.steps, args.warmup)
+        sync()
+        dt = time.perf_counter() - t0
+        eng.profile(False)
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        prof = {k: eng.profile_read(k) for k in ("painn_edge", "painn_update", "painn_embed", "painn_readout")}
+        assert bool(torch.isfinite(out).all())
+        eng.close()
+        return dt, prof
+
+    elapsed, prof = measure(args.precision)
+    n_edge, ms_edge = prof["painn_edge"]
+    n_upd, ms_upd = prof["painn_update"]
+    f32_leg = None
+    if args.precision != "f32" and not args.no_f32_leg:
+        dt32, prof32 = measure("f32")
+        f32_leg = {"value": world * B * args.steps / dt32, "ms_per_step": 1e3 * dt32 / args.steps,
+                   "edge_kernel_avg_ms": prof32["painn_edge"][1] / max(prof32["painn_edge"][0], 1),
+                   "edge_kernel_frac_of_f32_mfma_peak": B * E_M * FLOP_PER_EDGE_LAYER / (prof32["painn_edge"][1] / max(prof32["painn_edge"][0], 1) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
     if rank == 0:
         value = world * B * args.steps / elapsed
         edge_ms = ms_edge / max(n_edge, 1)
         achieved = B * E_M * FLOP_PER_EDGE_LAYER / (edge_ms * 1e-3) / 1e12 if n_edge else None
+        split = args.precision == "f16x2"
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         rec = {
             "metric": "integration-steps/sec (whole node)", "value": value, "unit": "trajectory-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via split-fp16 MFMA (hi + 2^-11 lo, fp32 accumulate)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 state and accumulation; matrix products on fp16 MFMA with 2-way split fp32 operands (hi + 2^-11 lo, 3 products)" if split else "f32", "data": "synthetic",
             "config": {"workload": "mdqm9 ambient sampler: 65536 molecules/GPU x 18 atoms (fully connected, 306 edges), cPaiNN F=128 L=5, "
                                    "Euler-Maruyama steps of the 1000-step grid, T1 over a 6-rung ladder",
                        "trajectories_per_gpu": B, "atoms": A, "n_features": F, "score_layers": L, "scheme": "em", "eps": args.eps,
                        "sharding": f"dp{world} over independent trajectories, final RCCL all-gather of end states"},
             "whole_step_tflops": FLOP_PER_MOL_EVAL * B * args.steps * world / elapsed / 1e12,
-            "roofline": {"kernel": "painn_edge_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, "traffic": None,
+            "roofline": {"kernel": "painn_edge_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak if achieved else None, "traffic": None,
+                         "peak_is": "dense fp16 MFMA (2.5 PF); the split path spends 3 fp16 products per algorithmic product, so its matrix-side ceiling is peak/3"
+                                    if split else "f32 MFMA (157.3 TF)",
                          "launches": n_edge, "avg_launch_ms": edge_ms, "update_kernel_avg_ms": ms_upd / max(n_upd, 1),
                          "flops_per_launch": B * E_M * FLOP_PER_EDGE_LAYER},
         }
+        if f32_leg:
+            rec["f32_mfma_path"] = f32_leg
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(ti, flat, template, args.cpu_sample)
         print(json.dumps(rec), flush=True)

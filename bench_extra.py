@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's contract line): adw double well (BASELINE config 2), mdqm9 latent (config 3),
+other molecule sizes / feature widths.  One JSON line per workload.  Needs a GPU."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="adw,latent,a9,a25,f256")
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    ti = importlib.import_module("thermodynamic-interpolation_amd")
+    syn, W = ti.synthetic, ti.weights
+    dev = torch.device("cuda", 0)
+    which = args.which.split(",")
+
+    def timed(fn):
+        fn(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(args.steps)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps
+
+    if "adw" in which:
+        # config 2: 262 144 particles, H=256, 5 layers, Euler-Maruyama; algorithmic 659 456 FLOP per particle-eval
+        B = 262144
+        flat = W.flatten_state_dict(syn.adw_state_dict(256, 5, 0), W.adw_param_spec(256, 5), dtype=np.float64)
+        eng = ti.engine.AdwEngine(256, 5, flat)
+        x0 = torch.from_numpy(syn.adw_x0(B, 0)).to(dev)
+        b0 = torch.full((B,), 1.0, device=dev)
+        b1 = torch.full((B,), 1.25, device=dev)
+        grid = ti.engine.time_grid(0.0, 1.0, 1001)
+        out = torch.empty((1, B), device=dev)
+        dt = timed(lambda k: eng.rollout(x0, b0, b1, grid[: k + 1], scheme="em", eps=0.01, seed=1, save_every=0, out=out))
+        print(json.dumps({"workload": "adw double well, 262144 particles, H=256 x 5 layers, EM step", "particle_steps_per_s": B / dt,
+                          "ms_per_step": dt * 1e3, "algorithmic_tflops": 659456 * B / dt / 1e12, "frac_f32_mfma_peak": 659456 * B / dt / 157.3e12}))
+
+    def painn(tag, variant, F, L, A, B, precision, cond_fn, temp_length):
+        src, dst, et = syn.fully_connected_template(A)
+        flat = W.flatten_state_dict(syn.painn_state_dict(variant, F, L, 25, 0), W.painn_param_spec(variant, F, L, 25))
+        eng = ti.engine.PainnEngine(variant, F, L, A, src, dst, et, np.arange(A), flat, temp_length=temp_length, precision=precision)
+        x0 = torch.from_numpy(syn.molecule_coords(B, A, 0, 1.0 if variant else 0.3)).to(dev)
+        c = cond_fn(B, A)
+        cond = None if c is None else torch.from_numpy(c).to(dev)
+        grid = ti.engine.time_grid(0.0, 1.0, 501)
+        out = torch.empty((1, B, A, 3), device=dev)
+        dt = timed(lambda k: eng.rollout(x0, cond, grid[: k + 1], scheme="euler", save_every=0, out=out))
+        nE = W.N_EMBED[variant]
+        flop = F * F * (L * (30 * A * (A - 1) + 24 * A) + (2 * nE + 4) * A + 4 * A) + 10 * F * A
+        print(json.dumps({"workload": tag, "precision": precision, "trajectory_steps_per_s": B / dt, "ms_per_step": dt * 1e3,
+                          "algorithmic_tflops": flop * B / dt / 1e12}))
+        eng.close()
+
+    for prec in ("f16x2", "f32"):
+        if "latent" in which:
+            painn("mdqm9 latent (config 3): 65536 molecules x 18 atoms, F=128 L=5, Euler ODE step", W.LATENT_MULTI, 128, 5, 18, 65536, prec,
+                  lambda B, A: syn.latent_cond(B, A, 800.0), 75.0)
+        if "a9" in which:
+            painn("ambient, molecule 00031 shape: 65536 x 9 atoms, F=128 L=5", W.AMBIENT, 128, 5, 9, 65536, prec, syn.ambient_cond, 100.0)
+        if "a25" in which:
+            painn("ambient, molecule 10506 shape: 16384 x 25 atoms, F=128 L=5", W.AMBIENT, 128, 5, 25, 16384, prec, syn.ambient_cond, 100.0)
+        if "f256" in which:
+            painn("ambient, 10506 config: 8192 x 25 atoms, F=256 L=5", W.AMBIENT, 256, 5, 25, 8192, prec, syn.ambient_cond, 100.0)
+
+
+if __name__ == "__main__":
+    main()
