@@ -146,8 +146,8 @@ struct PipeDMA {
             dma(g + (size_t)next * SUP4, base + (par ^ 1) * SUP4);
         }
         if (++sub == SC) {
-#ifndef TI_ABL_NOBARRIER         // ablation build (timing only, racy): no drain, no workgroup barrier at the superchunk boundary
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef TI_ABL_NOBARRIER         // ablation build (timing only, racy): no workgroup barrier at the superchunk boundary
             __syncthreads();
 #endif
             idx = (idx + 1 == nsup) ? 0 : idx + 1;
@@ -473,7 +473,9 @@ __device__ __forceinline__ void gemm_split_block(f32x4& acc, const Opnd<NBK, tru
         // fragment of the next k-step is read ahead; the compiler barrier keeps hipcc from hoisting ALL reads (64 VGPRs)
         const int nx = m + 1 < KS ? m + 1 : m;
         const h8 nh = wl[(nx * 2 + 0) * 64 + lane], nl = wl[(nx * 2 + 1) * 64 + lane];
+#ifndef TI_NO_LDS_FENCE
         asm volatile("" ::: "memory");
+#endif
         if (FLIP) { acc = mfma16h(in.hi[m], wh, acc); x = mfma16h(in.lo[m], wh, x); x = mfma16h(in.hi[m], wlo, x); }
         else      { acc = mfma16h(wh, in.hi[m], acc); x = mfma16h(wh, in.lo[m], x); x = mfma16h(wlo, in.hi[m], x); }
         wh = nh; wlo = nl;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -423,6 +424,7 @@ int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1,
     HIP_CHECK(hipMemcpyAsync(&flag, h->nanflag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (n_fevals) *n_fevals = fe;
+    if (flag && std::getenv("TI_IGNORE_NAN")) flag = 0;          // timing-only ablation builds produce garbage on purpose
     return flag ? fail(TI_E_NAN, "non-finite value in the final state") : TI_OK;
 }
 
