@@ -37,15 +37,19 @@ def main():
         # config 2: 262 144 particles, H=256, 5 layers, Euler-Maruyama; algorithmic 659 456 FLOP per particle-eval
         B = 262144
         flat = W.flatten_state_dict(syn.adw_state_dict(256, 5, 0), W.adw_param_spec(256, 5), dtype=np.float64)
-        eng = ti.engine.AdwEngine(256, 5, flat)
         x0 = torch.from_numpy(syn.adw_x0(B, 0)).to(dev)
         b0 = torch.full((B,), 1.0, device=dev)
         b1 = torch.full((B,), 1.25, device=dev)
         grid = ti.engine.time_grid(0.0, 1.0, 1001)
         out = torch.empty((1, B), device=dev)
-        dt = timed(lambda k: eng.rollout(x0, b0, b1, grid[: k + 1], scheme="em", eps=0.01, seed=1, save_every=0, out=out))
-        print(json.dumps({"workload": "adw double well, 262144 particles, H=256 x 5 layers, EM step", "particle_steps_per_s": B / dt,
-                          "ms_per_step": dt * 1e3, "algorithmic_tflops": 659456 * B / dt / 1e12, "frac_f32_mfma_peak": 659456 * B / dt / 157.3e12}))
+        for prec in ("f16x2", "f32"):
+            eng = ti.engine.AdwEngine(256, 5, flat, precision=prec)
+            dt = timed(lambda k: eng.rollout(x0, b0, b1, grid[: k + 1], scheme="em", eps=0.01, seed=1, save_every=0, out=out))
+            dtd = timed(lambda k: eng.rollout(x0, b0, b1, grid[: k + 1], scheme="euler", save_every=0, out=out, return_dlogp=True))
+            print(json.dumps({"workload": "adw double well (config 2): 262144 particles, H=256 x 5 layers", "precision": prec,
+                              "em_particle_steps_per_s": B / dt, "em_ms_per_step": dt * 1e3, "algorithmic_tflops": 659456 * B / dt / 1e12,
+                              "euler_with_dlogp_particle_steps_per_s": B / dtd, "euler_with_dlogp_ms_per_step": dtd * 1e3}))
+            eng.close()
 
     def painn(tag, variant, F, L, A, B, precision, cond_fn, temp_length):
         src, dst, et = syn.fully_connected_template(A)

@@ -82,6 +82,7 @@ typedef struct ti_painn_desc {
 typedef struct ti_adw_desc {
     int32_t hidden_size;    /* H: multiple of 32, <= 256 */
     int32_t num_layers;     /* number of hidden layers of `net` (reference: 5) */
+    int32_t precision;      /* TI_PREC_F32 | TI_PREC_F16X2 (as ti_painn_desc.precision) */
 } ti_adw_desc;
 
 typedef struct ti_rollout_desc {
@@ -107,9 +108,17 @@ const char* ti_last_error(void);
 ti_handle* ti_adw_create(const ti_adw_desc* desc, const double* weights, size_t n_weights, int device);
 /* b[i] = net([x_i, t, beta_embed([beta0_i, beta1_i, t])]);  x,beta0,beta1,out: [B] fp32 [host|device] */
 int ti_adw_drift(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out, int mem);
+/* also out_div[i] = d b_i / d x_i, the exact divergence of the 1-D drift by forward-mode differentiation of `net`
+ * (ODEWrapper.compute_divergence, adw/thermo/models/ode_wrapper.py:55-67, without its 1e-2 factor) */
+int ti_adw_drift_div(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out,
+                     float* out_div, int mem);
 /* out_path: [rows, B] fp32 with rows = ti_rollout_rows(...) */
 int ti_adw_rollout(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* beta0, const float* beta1,
                    int64_t B, float* out_path, int64_t* n_fevals);
+/* StandardIntegrator(return_dlogp=True) (adw/thermo/integrators.py:38-68): integrates the second state
+ * d(dlogp)/dt = -div * 1e-2 with the same scheme and writes out_dlogp [rows, B] = dlogp * 1e2 */
+int ti_adw_rollout_dlogp(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* beta0, const float* beta1,
+                         int64_t B, float* out_path, float* out_dlogp, int64_t* n_fevals);
 
 /* ---- mdqm9: cPaiNN drift over homogeneous molecule batches ------------------------------------------------------ */
 /* edge_src/edge_dst: [E_m] local atom indices of ONE molecule in the reference's (src,dst)-sorted order

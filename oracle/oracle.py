@@ -24,7 +24,7 @@ class PainnDesc(C.Structure):
 
 
 class AdwDesc(C.Structure):
-    _fields_ = [("hidden_size", C.c_int32), ("num_layers", C.c_int32)]
+    _fields_ = [("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("precision", C.c_int32)]
 
 
 class RolloutDesc(C.Structure):
@@ -133,7 +133,7 @@ class PainnOracle:
 
 class AdwOracle:
     def __init__(self, hidden, num_layers, flat_weights_f64):
-        self.desc = AdwDesc(hidden, num_layers)
+        self.desc = AdwDesc(hidden, num_layers, 0)
         w = np.ascontiguousarray(flat_weights_f64, np.float64)
         self.h = lib().tio_adw_create(C.byref(self.desc), _p(w, C.c_double), C.c_size_t(w.size))
         if not self.h:
@@ -147,14 +147,23 @@ class AdwOracle:
         fn(C.c_void_p(self.h), _p(x, ct), ct(t), _p(b0, ct), _p(b1, ct), C.c_int64(x.size), _p(out, ct))
         return out
 
-    def rollout(self, x0, beta0, beta1, t_grid, scheme="euler", save_every=1, **kw):
+    def drift_div(self, x, t, beta0, beta1):
+        """(b, d b / d x) in fp64; the reference's compute_divergence is d b / d x * 1e-2 (ode_wrapper.py:67)."""
+        x, b0, b1 = (np.ascontiguousarray(np.broadcast_to(a, np.shape(x)), np.float64) for a in (x, beta0, beta1))
+        out, div = np.empty_like(x), np.empty_like(x)
+        lib().tio_adw_drift_div_f64(C.c_void_p(self.h), _p(x, C.c_double), C.c_double(t), _p(b0, C.c_double), _p(b1, C.c_double),
+                                    C.c_int64(x.size), _p(out, C.c_double), _p(div, C.c_double))
+        return out, div
+
+    def rollout(self, x0, beta0, beta1, t_grid, scheme="euler", save_every=1, return_dlogp=False, **kw):
         x0, b0, b1 = (np.ascontiguousarray(np.broadcast_to(a, np.shape(x0)), np.float64) for a in (x0, beta0, beta1))
         rd = make_rollout_desc(scheme, t_grid, save_every, **kw)
         out = np.empty((rollout_rows(rd.n_step, save_every), x0.size), np.float64)
+        dl = np.empty_like(out) if return_dlogp else None
         nfe = C.c_int64(0)
         lib().tio_adw_rollout_f64(C.c_void_p(self.h), C.byref(rd), _p(x0, C.c_double), _p(b0, C.c_double), _p(b1, C.c_double),
-                                  C.c_int64(x0.size), _p(out, C.c_double), C.byref(nfe))
-        return out, nfe.value
+                                  C.c_int64(x0.size), _p(out, C.c_double), _p(dl, C.c_double), C.byref(nfe))
+        return (out, dl, nfe.value) if return_dlogp else (out, nfe.value)
 
 
 def normal(seed, traj, step, comp) -> float:

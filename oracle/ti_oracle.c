@@ -185,40 +185,50 @@ void* tio_adw_create(const ti_adw_desc* d, const double* w, size_t n)
 void tio_adw_destroy(void* hv) { free(hv); }
 
 int tio_adw_drift_f64(void* hv, const double* x, double t, const double* b0, const double* b1, int64_t B, double* out)
-{ adw_drift_f64(((tio_adw*)hv)->m64, x, t, b0, b1, B, out); return 0; }
+{ adw_drift_f64(((tio_adw*)hv)->m64, x, t, b0, b1, B, out, NULL); return 0; }
+
+/* drift and d b / d x (the reference's divergence before its 1e-2 scaling) */
+int tio_adw_drift_div_f64(void* hv, const double* x, double t, const double* b0, const double* b1, int64_t B, double* out, double* div)
+{ adw_drift_f64(((tio_adw*)hv)->m64, x, t, b0, b1, B, out, div); return 0; }
 
 int tio_adw_drift_f32(void* hv, const float* x, float t, const float* b0, const float* b1, int64_t B, float* out)
-{ adw_drift_f32(((tio_adw*)hv)->m32, x, t, b0, b1, B, out); return 0; }
+{ adw_drift_f32(((tio_adw*)hv)->m32, x, t, b0, b1, B, out, NULL); return 0; }
 
 /* fp64 rollout (the reference's adw precision).  out_path [rows,B] */
+/* out_dlogp (may be NULL): the reference's second state, d(dlogp)/dt = -div * 1e-2, returned * 1e2 (integrators.py:68) */
 int tio_adw_rollout_f64(void* hv, const ti_rollout_desc* rd, const double* x0, const double* b0, const double* b1v, int64_t B,
-                        double* out_path, int64_t* n_fevals)
+                        double* out_path, double* out_dlogp, int64_t* n_fevals)
 {
     tio_adw* h = hv; const size_t n = (size_t)B;
     double *x = malloc(8 * n), *k1 = malloc(8 * n), *k2 = malloc(8 * n), *xt = malloc(8 * n);
+    double *dl = calloc(n, 8), *d1 = malloc(8 * n), *d2 = malloc(8 * n);
     memcpy(x, x0, 8 * n);
     int64_t row = 0, fe = 0;
-    if (rd->save_every > 0) memcpy(out_path + (row++) * n, x, 8 * n);
+#define SAVE_ROW() do { if (out_dlogp) for (size_t i = 0; i < n; ++i) out_dlogp[row * n + i] = dl[i] * 1e2; memcpy(out_path + (row++) * n, x, 8 * n); } while (0)
+    if (rd->save_every > 0) SAVE_ROW();
     for (int k = 0; k < rd->n_step - 1; ++k) {
         const double dt = (double)rd->t_grid[k + 1] - (double)rd->t_grid[k];
-        adw_drift_f64(h->m64, x, (double)rd->t_grid[k], b0, b1v, B, k1); ++fe;
+        adw_drift_f64(h->m64, x, (double)rd->t_grid[k], b0, b1v, B, k1, out_dlogp ? d1 : NULL); ++fe;
         if (rd->scheme == TI_SCHEME_HEUN) {
             for (size_t i = 0; i < n; ++i) xt[i] = x[i] + dt * k1[i];
-            adw_drift_f64(h->m64, xt, (double)rd->t_grid[k + 1], b0, b1v, B, k2); ++fe;
+            adw_drift_f64(h->m64, xt, (double)rd->t_grid[k + 1], b0, b1v, B, k2, out_dlogp ? d2 : NULL); ++fe;
             for (size_t i = 0; i < n; ++i) x[i] = x[i] + 0.5 * dt * (k1[i] + k2[i]);
+            if (out_dlogp) for (size_t i = 0; i < n; ++i) dl[i] = dl[i] + 0.5 * dt * (-(d1[i] + d2[i]) * 1e-2);
         } else {
             for (size_t i = 0; i < n; ++i) x[i] = x[i] + dt * k1[i];
+            if (out_dlogp) for (size_t i = 0; i < n; ++i) dl[i] = dl[i] + dt * (-d1[i] * 1e-2);
             if (rd->scheme == TI_SCHEME_EM && rd->eps > 0.0f) {
                 const float sig = sqrtf(2.0f * rd->eps * fabsf((float)dt));
                 for (size_t i = 0; i < n; ++i) x[i] += (double)(sig * ti_normal(rd->seed, rd->traj_offset + (int64_t)i, k, 0));
             }
         }
         const int step = k + 1;
-        if (rd->save_every > 0 && (step % rd->save_every == 0 || step == rd->n_step - 1)) memcpy(out_path + (row++) * n, x, 8 * n);
+        if (rd->save_every > 0 && (step % rd->save_every == 0 || step == rd->n_step - 1)) SAVE_ROW();
     }
-    if (rd->save_every <= 0) memcpy(out_path, x, 8 * n);
+    if (rd->save_every <= 0) SAVE_ROW();
+#undef SAVE_ROW
     if (n_fevals) *n_fevals = fe;
-    free(x); free(k1); free(k2); free(xt);
+    free(x); free(k1); free(k2); free(xt); free(dl); free(d1); free(d2);
     return 0;
 }
 

@@ -311,13 +311,15 @@ static FN(adw_t)* FN(adw_parse)(const ti_adw_desc* d, const double* w, size_t n)
 
 static void FN(silu_rows)(REAL* x, size_t n) { for (size_t i = 0; i < n; ++i) x[i] = x[i] / ((REAL)1 + REXP(-x[i])); }
 
-/* FCNetMultiBeta.forward (simple.py:38-41) through ODEWrapper.forward (adw ode_wrapper.py:47-52): ts = ones_like(x)*t */
-static void FN(adw_drift)(const FN(adw_t)* m, const REAL* x, REAL t, const REAL* beta0, const REAL* beta1, long B, REAL* out)
+/* FCNetMultiBeta.forward (simple.py:38-41) through ODEWrapper.forward (adw ode_wrapper.py:47-52): ts = ones_like(x)*t.
+ * If `div` is not NULL it receives d b / d x (ODEWrapper.compute_divergence, ode_wrapper.py:55-67, WITHOUT its 1e-2 factor),
+ * by forward-mode differentiation of `net` (beta_embed does not depend on x): tangent of [x, t, emb] is [1, 0, 0]. */
+static void FN(adw_drift)(const FN(adw_t)* m, const REAL* x, REAL t, const REAL* beta0, const REAL* beta1, long B, REAL* out, REAL* div)
 {
     const int H = m->H;
 #pragma omp parallel
     {
-        REAL* h1 = malloc(sizeof(REAL) * 2 * H); REAL* h2 = h1 + H;
+        REAL* h1 = malloc(sizeof(REAL) * 4 * H); REAL* h2 = h1 + H; REAL* d1 = h2 + H; REAL* d2 = d1 + H;
 #pragma omp for
         for (long i = 0; i < B; ++i) {
             REAL in[3] = { beta0[i], beta1[i], t }, emb;
@@ -325,11 +327,20 @@ static void FN(adw_drift)(const FN(adw_t)* m, const REAL* x, REAL t, const REAL*
             FN(linear)(h1, 1, H, H, m->be_W1t, m->be_b1, H, h2, H); FN(silu_rows)(h2, H);
             emb = m->be_b2[0]; for (int k = 0; k < H; ++k) emb += h2[k] * m->be_W2[k];
             REAL in2[3] = { x[i], t, emb };
-            FN(linear)(in2, 1, 3, 3, m->Wt[0], m->b[0], H, h1, H); FN(silu_rows)(h1, H);
-            REAL *a = h1, *b = h2;
-            for (int l = 1; l < m->nl; ++l) { FN(linear)(a, 1, H, H, m->Wt[l], m->b[l], H, b, H); FN(silu_rows)(b, H); REAL* tsw = a; a = b; b = tsw; }
-            REAL o = m->b[m->nl][0]; for (int k = 0; k < H; ++k) o += a[k] * m->Wt[m->nl][k];
+            FN(linear)(in2, 1, 3, 3, m->Wt[0], m->b[0], H, h1, H);
+            /* silu'(z) = sig(z) * (1 + z * (1 - sig(z))) */
+            for (int k = 0; k < H; ++k) { const REAL z = h1[k], sg = (REAL)1 / ((REAL)1 + REXP(-z)); d1[k] = sg * ((REAL)1 + z * ((REAL)1 - sg)) * m->Wt[0][k]; h1[k] = z * sg; }
+            REAL *a = h1, *b = h2, *da = d1, *db = d2;
+            for (int l = 1; l < m->nl; ++l) {
+                FN(linear)(a, 1, H, H, m->Wt[l], m->b[l], H, b, H);
+                FN(linear)(da, 1, H, H, m->Wt[l], NULL, H, db, H);
+                for (int k = 0; k < H; ++k) { const REAL z = b[k], sg = (REAL)1 / ((REAL)1 + REXP(-z)); db[k] = sg * ((REAL)1 + z * ((REAL)1 - sg)) * db[k]; b[k] = z * sg; }
+                REAL* tsw = a; a = b; b = tsw; tsw = da; da = db; db = tsw;
+            }
+            REAL o = m->b[m->nl][0], dd = 0;
+            for (int k = 0; k < H; ++k) { o += a[k] * m->Wt[m->nl][k]; dd += da[k] * m->Wt[m->nl][k]; }
             out[i] = o;
+            if (div) div[i] = dd;
         }
         free(h1);
     }

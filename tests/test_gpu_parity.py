@@ -234,3 +234,51 @@ def test_split_fp16_precision_mode_meets_the_same_bar(name):
         err, err32 = rel_l2(got, g[f"drift_{i}"]), rel_l2(ref32.drift(g["x"], float(t), g["cond"]), g[f"drift_{i}"])
         print(f"\n[split-fp16] {name} t={float(t):.2f}: rel-L2 vs reference {err:.2e} (f32-MFMA path {err32:.2e})")
         assert np.isfinite(got).all() and err < DRIFT_TOL, (name, i, err)
+
+
+# ------------------------------------------------------------------------------------- adw divergence / dlogp, split mode
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("name", ["adw_h256", "adw_ctor_h64"])
+def test_adw_divergence_and_dlogp(name, precision):
+    """Exact divergence by forward-mode differentiation of `net` against the reference's autograd value
+    (ODEWrapper.compute_divergence, golden key negdiv* = -div * 1e-2 at t = 0.3), and the integrated dlogp state of
+    StandardIntegrator(return_dlogp=True) against the oracle's fp64 rollout."""
+    ti = pkg()
+    g = load_golden(name)
+    H, nl = int(g["hidden"]), int(g["num_layers"])
+    sd = {k[4:]: v for k, v in g.items() if k.startswith("sd::")} or ti.synthetic.adw_state_dict(H, nl, int(g["seed"]))
+    flat = ti.weights.flatten_state_dict(sd, ti.weights.adw_param_spec(H, nl), dtype=np.float64)
+    eng, orc = ti.engine.AdwEngine(H, nl, flat, precision=precision), oracle.AdwOracle(H, nl, flat)
+    for tag in ("", "_var"):
+        b0, b1 = g["beta0" + tag].astype(np.float32), g["beta1" + tag].astype(np.float32)
+        b, div = eng.drift(g["x"], 0.3, b0, b1, return_div=True)
+        assert rel_l2(-div * 1e-2, g[f"negdiv{tag}_1"].ravel()) < DRIFT_TOL, (tag, precision)
+        for i, t in enumerate(g["ts"]):
+            assert rel_l2(eng.drift(g["x"], float(t), b0, b1), g[f"drift{tag}_{i}"]) < DRIFT_TOL, (tag, i, precision)
+    b0, b1 = g["beta0"].astype(np.float32), g["beta1"].astype(np.float32)
+    for scheme in ("euler", "heun"):
+        x, dl, nfe = eng.rollout(g["x"], b0, b1, g["traj_grid"], scheme=scheme, return_dlogp=True)
+        xr, dlr, _ = orc.rollout(g["x"].astype(np.float64), b0, b1, g["traj_grid"], scheme=scheme, return_dlogp=True)
+        assert x.shape == dl.shape == xr.shape and np.all(dl[0] == 0)
+        assert rel_l2(x, xr) < DRIFT_TOL and rel_l2(dl, dlr) < 2e-5, (scheme, precision)
+        x2, _ = eng.rollout(g["x"], b0, b1, g["traj_grid"], scheme=scheme)
+        np.testing.assert_array_equal(x, x2)                         # the dlogp state does not perturb the trajectory
+
+
+def test_adw_standard_integrator_with_dlogp_like_the_shipped_config():
+    """adw/config/settings.json ships return_dlogp = 1: rollout returns (x [n_step,B,1], dlogp*1e2 [n_step,B,1])."""
+    torch = pytest.importorskip("torch")
+    ti = pkg()
+    g = load_golden("adw_ctor_h64")
+    net = ti.thermo.adw.FCNetMultiBeta(1, 1, int(g["hidden"]), int(g["num_layers"]))
+    net.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")})
+    x0s = torch.from_numpy(g["x"])[:, None]
+    beta0s = torch.from_numpy(g["beta0"])[:, None]
+    beta1s = torch.ones_like(beta0s) * 1.25
+    n_step = len(g["traj_grid"])
+    integ = ti.thermo.adw.StandardIntegrator(b=net, method="heun", rtol=1e-4, atol=1e-4, n_step=n_step, return_dlogp=1)
+    sample, dlogp = integ.rollout(x0s, beta0s=beta0s, beta1s=beta1s)
+    assert tuple(sample.shape) == tuple(dlogp.shape) == (n_step, len(g["x"]), 1)
+    assert rel_l2(sample.numpy()[:, :, 0], g["traj_heun"]) < 1e-5
+    b, negdiv = ti.thermo.adw.ODEWrapper(net, return_dlogp=True)(0.3, (x0s, None), None, beta0s, beta1s)
+    assert rel_l2(negdiv.numpy().ravel(), g["negdiv_1"].ravel()) < 1e-5

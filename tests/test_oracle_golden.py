@@ -107,3 +107,13 @@ def test_adw_drift_and_trajectory(name):
     for scheme in ("euler", "heun"):
         path, _ = o.rollout(g["x"].astype(np.float64), g["beta0"], g["beta1"], g["traj_grid"], scheme=scheme)
         assert rel_l2(path, g[f"traj_{scheme}"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["adw_h256", "adw_ctor_h64"])
+def test_adw_divergence_matches_reference_autograd(name):
+    """ODEWrapper.compute_divergence (adw/thermo/models/ode_wrapper.py:55-67): the golden holds -div * 1e-2 from autograd."""
+    g = load_golden(name)
+    o = adw_oracle(g)
+    for tag in ("", "_var"):
+        b, div = o.drift_div(g["x"].astype(np.float64), 0.3, g["beta0" + tag], g["beta1" + tag])   # the generator used t = 0.3 (fp64)
+        assert rel_l2(-div * 1e-2, g[f"negdiv{tag}_1"].ravel()) < 1e-10

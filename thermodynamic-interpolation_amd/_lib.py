@@ -22,7 +22,7 @@ KERNELS = {"painn_edge": 0, "painn_update": 1, "painn_embed": 2, "painn_readout"
 # every symbol include/ti_hip.h declares (tests/test_abi.py checks the library exports exactly these)
 ABI_SYMBOLS = [
     "ti_rollout_rows", "ti_version", "ti_device_count", "ti_last_error",
-    "ti_adw_create", "ti_adw_drift", "ti_adw_rollout",
+    "ti_adw_create", "ti_adw_drift", "ti_adw_drift_div", "ti_adw_rollout", "ti_adw_rollout_dlogp",
     "ti_painn_create", "ti_painn_drift", "ti_painn_rollout",
     "ti_destroy", "ti_set_stream", "ti_reserve", "ti_profile_enable", "ti_profile_read",
     "ti_painn_debug_tap", "ti_painn_debug_read", "ti_selftest",
@@ -36,7 +36,7 @@ class PainnDesc(C.Structure):
 
 
 class AdwDesc(C.Structure):
-    _fields_ = [("hidden_size", C.c_int32), ("num_layers", C.c_int32)]
+    _fields_ = [("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("precision", C.c_int32)]
 
 
 class RolloutDesc(C.Structure):
@@ -93,6 +93,8 @@ def lib():
     L.ti_adw_create.argtypes = [C.POINTER(AdwDesc), C.POINTER(C.c_double), C.c_size_t, C.c_int]
     L.ti_adw_drift.argtypes = [vp, vp, C.c_float, vp, vp, C.c_int64, vp, C.c_int]
     L.ti_adw_rollout.argtypes = [vp, C.POINTER(RolloutDesc), vp, vp, vp, C.c_int64, vp, C.POINTER(C.c_int64)]
+    L.ti_adw_drift_div.argtypes = [vp, vp, C.c_float, vp, vp, C.c_int64, vp, vp, C.c_int]
+    L.ti_adw_rollout_dlogp.argtypes = [vp, C.POINTER(RolloutDesc), vp, vp, vp, C.c_int64, vp, vp, C.POINTER(C.c_int64)]
     L.ti_destroy.argtypes = [vp]
     L.ti_destroy.restype = None
     L.ti_set_stream.argtypes = [vp, vp]

@@ -3,86 +3,142 @@
 // Restates /root/reference/adw/thermo/models/simple.py:22-41.  Both MLPs of the model have the same shape
 //   Linear(3 -> H), SiLU, [Linear(H -> H), SiLU] x n_hidden, Linear(H -> 1)
 // (beta_embed: inputs [beta0, beta1, t], n_hidden = 1;  net: inputs [x, t, beta_embed], n_hidden = num_layers-1),
-// so one kernel serves both: 32 rows per wave, hidden activations in registers, H x H layers on the f32 MFMA.
+// so one kernel serves both: hidden activations stay in registers, H x H layers on the matrix cores.
 #include "mfma_chain.hpp"
 #include "ti_internal.hpp"
 
 namespace ti {
 
-template <int NB, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void adw_mlp_kernel(const AdwParams p)
+// Per-MLP vector block in LDS (floats): w_in [H][3] | b_in [H] | b_hidden [n_hidden][H] | w_out [H]
+//
+// 16 rows per wave on the r16 primitives (mfma_chain.hpp), f32 or split-fp16 matrix path.  TAN additionally propagates the
+// tangent d/d(a0) through the network (forward mode): out_div = d out / d a0, which for `net` is the divergence of the 1-D
+// drift, ODEWrapper.compute_divergence (/root/reference/adw/thermo/models/ode_wrapper.py:55-67) without its 1e-2 factor.
+template <int NBK, bool SPLIT, bool TAN>
+__global__ __launch_bounds__(256, (NBK <= 8 && !TAN) ? 2 : 1) void adw_mlp_kernel(const AdwParams p)
 {
-    constexpr int H = 32 * NB, T = 64 * WAVES, CH4 = 256 * NB;
+    constexpr int H = 16 * NBK, NB = (H + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
     extern __shared__ f32x4 lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    Pipe<NB, T> pipe;
-    if (p.nch > 0) pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);
-    (void)CH4;
-    const long long row = ((long long)blockIdx.x * WAVES + wave) * 32 + j;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    float* vec = reinterpret_cast<float*>(lds + 2 * CH4);
+    const int nvec4 = (5 + p.n_hidden) * H / 4;
+    for (int i = threadIdx.x; i < nvec4; i += T) reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
+    PipeDMA<NB, T, 1> pipe;
+    if (p.nch > 0) pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+    else __syncthreads();
+    const float* w_in = vec;
+    const float* b_in = vec + 3 * H;
+    const float* b_hid = vec + 4 * H;
+    const float* w_out = vec + (4 + p.n_hidden) * H;
+
+    const long long row = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
     const bool ok = row < p.B;
     const long long r = ok ? row : p.B - 1;
     const float a0 = p.x[r];
     const float a1 = p.in1 ? p.in1[r] : p.t;
     const float a2 = p.idx ? p.emb[p.idx[r]] : (p.emb ? p.emb[r] : p.t);
 
+    // silu(z) = z * sig(z);  silu'(z) = sig(z) + silu(z) * (1 - sig(z))
+    auto act = [](float z, float& y, float& dy) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+        y = z * sg;
+        dy = fmaf(y, 1.0f - sg, sg);
+    };
     // input layer (K = 3): plain FMAs straight into the register layout
-    Act<NB> cur;
+    A16 cur, tan;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const f32x16 b = load_block(p.b_in, nb, h);
+    for (int nb = 0; nb < NBK; ++nb) {
+        const float* w = w_in + (16 * nb + 4 * q) * 3;                     // rows f..f+3 of W_in[H][3]
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 4),
+                    w2 = *reinterpret_cast<const f32x4*>(w + 8);
+        const float ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+        const f32x4 bb = r16::load_block(b_in, nb, q);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float* w = p.w_in + (32 * nb + 8 * g + 4 * h) * 3;      // rows f..f+3 of W_in[H][3]
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 4),
-                        w2 = *reinterpret_cast<const f32x4*>(w + 8);
-            const float ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                cur.b[nb][4 * g + q] = silu(fmaf(ww[3 * q + 2], a2, fmaf(ww[3 * q + 1], a1, fmaf(ww[3 * q], a0, b[4 * g + q]))));
+        for (int k = 0; k < 4; ++k) {
+            const float z = fmaf(ww[3 * k + 2], a2, fmaf(ww[3 * k + 1], a1, fmaf(ww[3 * k], a0, bb[k])));
+            float y, dy;
+            act(z, y, dy);
+            cur.b[nb][k] = y;
+            if (TAN) tan.b[nb][k] = dy * ww[3 * k];
         }
     }
     // hidden layers
     for (int l = 0; l < p.n_hidden; ++l) {
-        Act<NB> nxt;
-        const float* bias = p.b_hidden + (size_t)l * H;
+        OP in, tin;
+        in.set(cur);
+        if (TAN) tin.set(tan);
+        const float* bias = b_hid + (size_t)l * H;
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) {
-            const f32x4* wl = pipe.begin();
-            f32x16 a = load_block(bias, nbo, h);
-            gemm_bt(a, cur, wl, lane);
-            pipe.end();
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 z0 = r16::load_block(bias, 2 * ch, q), z1 = r16::load_block(bias, 2 * ch + 1, q);
+            r16::gemm_bt(z0, z1, in, wl, lane);
+            f32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+            if (TAN) r16::gemm_bt(t0, t1, tin, wl, lane);
+            pipe.release();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) nxt.b[nbo][i] = silu(a[i]);
+            for (int k = 0; k < 4; ++k) {
+                float y, dy;
+                act(z0[k], y, dy); cur.b[2 * ch][k] = y;     if (TAN) tan.b[2 * ch][k] = dy * t0[k];
+                act(z1[k], y, dy); cur.b[2 * ch + 1][k] = y; if (TAN) tan.b[2 * ch + 1][k] = dy * t1[k];
+            }
         }
-        cur = nxt;
     }
-    const float o = dot_set(cur, p.w_out, h) + p.b_out;
-    if (ok && h == 0) p.out[row] = o;
+    float o = 0.f, d = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const f32x4 w = r16::load_block(w_out, nb, q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o = fmaf(cur.b[nb][k], w[k], o); if (TAN) d = fmaf(tan.b[nb][k], w[k], d); }
+    }
+    o = r16::xquarters(o) + p.b_out;
+    if (TAN) d = r16::xquarters(d);
+    if (ok && q == 0) { p.out[row] = o; if (TAN) p.out_div[row] = d; }
 }
+
+static size_t adw_lds_bytes(int NB, int n_hidden) { return 2 * (size_t)256 * NB * 16 + (size_t)(5 + n_hidden) * 32 * NB * 4; }
 
 #define TI_DISPATCH_NB(NBv, ...) \
     switch (NBv) {                                                            \
-        case 1: { constexpr int NB = 1, WAVES = 8; __VA_ARGS__; } break;             \
-        case 2: { constexpr int NB = 2, WAVES = 8; __VA_ARGS__; } break;             \
-        case 4: { constexpr int NB = 4, WAVES = 8; __VA_ARGS__; } break;             \
-        case 8: { constexpr int NB = 8, WAVES = 4; __VA_ARGS__; } break;             \
+        case 1: { constexpr int NB = 1; __VA_ARGS__; } break;                 \
+        case 2: { constexpr int NB = 2; __VA_ARGS__; } break;                 \
+        case 4: { constexpr int NB = 4; __VA_ARGS__; } break;                 \
+        case 8: { constexpr int NB = 8; __VA_ARGS__; } break;                 \
         default: return hipErrorInvalidValue;                                 \
     }
 
-hipError_t configure_adw_kernels(int NBv)
+template <int NBK>
+static hipError_t adw_set_attrs(size_t bytes)
 {
-    TI_DISPATCH_NB(NBv, {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(adw_mlp_kernel<NB, WAVES>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * NB * 16);
-    });
+    hipError_t e;
+#define TI_SET(k) if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)) != hipSuccess) return e
+    TI_SET((adw_mlp_kernel<NBK, false, false>)); TI_SET((adw_mlp_kernel<NBK, true, false>));
+    TI_SET((adw_mlp_kernel<NBK, false, true>)); TI_SET((adw_mlp_kernel<NBK, true, true>));
+#undef TI_SET
     return hipSuccess;
 }
 
-hipError_t launch_adw(int NBv, const AdwParams& p, hipStream_t st)
+hipError_t configure_adw_kernels(int NBv, int max_hidden)
+{
+    TI_DISPATCH_NB(NBv, return (adw_set_attrs<2 * NB>(adw_lds_bytes(NB, max_hidden))));
+    return hipSuccess;
+}
+
+hipError_t launch_adw(int NBv, bool split, const AdwParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
-        const dim3 g((unsigned)((p.B + 32LL * WAVES - 1) / (32LL * WAVES)));
-        hipLaunchKernelGGL((adw_mlp_kernel<NB, WAVES>), g, dim3(64 * WAVES), 2 * 256 * NB * 16, st, p);
+        const dim3 g((unsigned)((p.B + 63) / 64));
+        const size_t l = adw_lds_bytes(NB, p.n_hidden);
+        const bool tanv = p.out_div != nullptr;
+        if (split) {
+            if (tanv) hipLaunchKernelGGL((adw_mlp_kernel<2 * NB, true, true>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((adw_mlp_kernel<2 * NB, true, false>), g, dim3(256), l, st, p);
+        } else {
+            if (tanv) hipLaunchKernelGGL((adw_mlp_kernel<2 * NB, false, true>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((adw_mlp_kernel<2 * NB, false, false>), g, dim3(256), l, st, p);
+        }
     });
     return hipGetLastError();
 }
@@ -140,6 +196,12 @@ __global__ void noise_kernel(float* __restrict__ x, float sigma, uint64_t seed, 
     }
 }
 
+__global__ void scale_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * a;
+}
+
 __global__ void nan_check_kernel(const float* __restrict__ x, long long n, int* flag)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,6 +236,11 @@ hipError_t launch_noise(float* x, float sigma, uint64_t seed, long long traj0, i
                         hipStream_t st)
 {
     if (B > 0) hipLaunchKernelGGL(noise_kernel, grid1(B, 128), dim3(128), 0, st, x, sigma, seed, traj0, step, B, comps, atoms_for_com);
+    return hipGetLastError();
+}
+hipError_t launch_scale(float* y, const float* x, float a, long long n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(scale_kernel, grid1(n, 256), dim3(256), 0, st, y, x, a, n);
     return hipGetLastError();
 }
 hipError_t launch_selftest(float* out, hipStream_t st)

@@ -124,11 +124,10 @@ struct ti_handle {
 
     // ---- adw
     ti_adw_desc ad{};
-    size_t a_be_w_in = 0, a_be_b_in = 0, a_be_b_h = 0, a_be_w_out = 0, a_w_in = 0, a_b_in = 0, a_b_h = 0, a_w_out = 0;
+    size_t a_be_vecs = 0, a_net_vecs = 0;          // offsets of the per-MLP vector blocks in `flat`
     float a_be_b_out = 0.f, a_b_out = 0.f;
     Stream st_be{}, st_net{};
-    DevBuf<float> ax, ab1, ab2, axt, aemb_u, abeta0_u, abeta1_u; DevBuf<int32_t> aidx;
-    long long U_cap = 0;
+    DevBuf<float> ax, ab1, ab2, axt, aemb_u, abeta0_u, abeta1_u, adl, ad1, ad2; DevBuf<int32_t> aidx;
 
     ~ti_handle()
     {
@@ -341,17 +340,16 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
 
 // ------------------------------------------------------------------------------------------------ adw helpers
 void adw_mlp_launch(ti_handle* h, bool embed, const float* a0, const float* in1, const float* emb, const int32_t* idx, float t,
-                    long long rows, float* out)
+                    long long rows, float* out, float* out_div)
 {
     AdwParams p{};
     const Stream& s2 = embed ? h->st_be : h->st_net;
     p.stream = h->S(s2); p.nch = s2.nch;
-    p.w_in = h->F(embed ? h->a_be_w_in : h->a_w_in); p.b_in = h->F(embed ? h->a_be_b_in : h->a_b_in);
-    p.b_hidden = h->F(embed ? h->a_be_b_h : h->a_b_h); p.w_out = h->F(embed ? h->a_be_w_out : h->a_w_out);
+    p.vecs = h->F(embed ? h->a_be_vecs : h->a_net_vecs);
     p.b_out = embed ? h->a_be_b_out : h->a_b_out; p.n_hidden = embed ? 1 : h->ad.num_layers - 1; p.B = rows;
-    p.x = a0; p.in1 = in1; p.emb = emb; p.idx = idx; p.t = t; p.out = out;
+    p.x = a0; p.in1 = in1; p.emb = emb; p.idx = idx; p.t = t; p.out = out; p.out_div = out_div;
     Timed tm(h, TI_KERNEL_ADW);
-    HIP_CHECK(launch_adw(h->NB, p, h->stream));
+    HIP_CHECK(launch_adw(h->NB, h->ad.precision == TI_PREC_F16X2, p, h->stream));
 }
 
 // upload conditioning: dedupe (beta0, beta1) pairs on the host (the driver uses one pair, adw/sample.py:24)
@@ -376,40 +374,54 @@ long long adw_set_cond(ti_handle* h, const float* beta0, const float* beta1, lon
     return (long long)u0.size();
 }
 
-void adw_drift_dev(ti_handle* h, const float* x_dev, float t, long long U, long long B, float* out_dev)
+// out_div (may be NULL): d b / d x, the divergence of the 1-D drift (beta_embed does not depend on x)
+void adw_drift_dev(ti_handle* h, const float* x_dev, float t, long long U, long long B, float* out_dev, float* out_div)
 {
-    adw_mlp_launch(h, true, h->abeta0_u.p, h->abeta1_u.p, nullptr, nullptr, t, U, h->aemb_u.p);     // beta_embed([b0, b1, t])
-    adw_mlp_launch(h, false, x_dev, nullptr, h->aemb_u.p, h->aidx.p, t, B, out_dev);               // net([x, t, embed])
+    adw_mlp_launch(h, true, h->abeta0_u.p, h->abeta1_u.p, nullptr, nullptr, t, U, h->aemb_u.p, nullptr);   // beta_embed([b0, b1, t])
+    adw_mlp_launch(h, false, x_dev, nullptr, h->aemb_u.p, h->aidx.p, t, B, out_dev, out_div);             // net([x, t, embed])
 }
 
 void ensure_adw_ws(ti_handle* h, long long B)
 {
     if (B <= h->cap) return;
-    h->ax.alloc(B); h->ab1.alloc(B); h->ab2.alloc(B); h->axt.alloc(B);
+    h->ax.alloc(B); h->ab1.alloc(B); h->ab2.alloc(B); h->axt.alloc(B); h->adl.alloc(B); h->ad1.alloc(B); h->ad2.alloc(B);
     h->cap = B;
 }
 
 // ------------------------------------------------------------------------------------------------ shared rollout
 // drift(x_dev, t, out_dev) evaluates the drift; state arrays have n floats; comps = floats per trajectory
+// Optional second state of the reference ODE: d(dlogp)/dt = -div * 1e-2, returned * 1e2 (adw/thermo/integrators.py:38-68).
+struct DlogpAux { float *dl = nullptr, *d1 = nullptr, *d2 = nullptr, *scaled = nullptr, *out = nullptr; };
+
+// drift(x_dev, t, out_b, out_div) evaluates the drift (and the divergence if out_div != NULL); state arrays have n floats
 template <typename Drift>
 int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1, float* b2, float* xt, size_t n, long long B, int comps,
-                   int atoms_for_com, float* out_path, int64_t* n_fevals, Drift&& drift)
+                   int atoms_for_com, float* out_path, int64_t* n_fevals, Drift&& drift, DlogpAux aux = DlogpAux())
 {
     hipStream_t st = h->stream;
     const hipMemcpyKind out_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     int64_t row = 0, fe = 0;
-    auto save = [&]() { HIP_CHECK(hipMemcpyAsync(out_path + (size_t)(row++) * n, x, n * sizeof(float), out_kind, st)); };
+    if (aux.dl) HIP_CHECK(hipMemsetAsync(aux.dl, 0, n * sizeof(float), st));
+    auto save = [&]() {
+        if (aux.dl) {
+            HIP_CHECK(launch_scale(aux.scaled, aux.dl, 100.0f, (long long)n, st));
+            HIP_CHECK(hipMemcpyAsync(aux.out + (size_t)row * n, aux.scaled, n * sizeof(float), out_kind, st));
+        }
+        HIP_CHECK(hipMemcpyAsync(out_path + (size_t)(row++) * n, x, n * sizeof(float), out_kind, st));
+    };
     if (rd->save_every > 0) save();
     for (int k = 0; k < rd->n_step - 1; ++k) {
         const float dt = rd->t_grid[k + 1] - rd->t_grid[k];
-        drift(x, rd->t_grid[k], b1); ++fe;
+        drift(x, rd->t_grid[k], b1, aux.d1); ++fe;
         if (rd->scheme == TI_SCHEME_HEUN) {
             { Timed tm(h, TI_KERNEL_INTEGRATE); HIP_CHECK(launch_axpy(xt, x, dt, b1, (long long)n, st)); }
-            drift(xt, rd->t_grid[k + 1], b2); ++fe;
+            drift(xt, rd->t_grid[k + 1], b2, aux.d2); ++fe;
             { Timed tm(h, TI_KERNEL_INTEGRATE); HIP_CHECK(launch_heun(x, 0.5f * dt, b1, b2, (long long)n, st)); }
+            if (aux.dl) HIP_CHECK(launch_heun(aux.dl, -0.5f * dt * 1e-2f, aux.d1, aux.d2, (long long)n, st));
         } else {
             Timed tm(h, TI_KERNEL_INTEGRATE);
             HIP_CHECK(launch_axpy(x, x, dt, b1, (long long)n, st));
+            if (aux.dl) HIP_CHECK(launch_axpy(aux.dl, aux.dl, -dt * 1e-2f, aux.d1, (long long)n, st));
             if (rd->scheme == TI_SCHEME_EM && rd->eps > 0.0f)
                 HIP_CHECK(launch_noise(x, std::sqrt(2.0f * rd->eps * std::fabs(dt)), rd->seed, rd->traj_offset, k, B, comps,
                                        rd->com_free_noise ? atoms_for_com : 0, st));
@@ -583,7 +595,7 @@ int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, c
         if (rd->mem == TI_MEM_HOST && nc) { HIP_CHECK(hipMemcpyAsync(h->cond.p, cond, nc * sizeof(float), hipMemcpyHostToDevice, h->stream)); cd = h->cond.p; }
         const int saved_tap = h->tap; h->tap = -1;
         const int rc = rollout_common(h, rd, h->x.p, h->b1.p, h->b2.p, h->xt.p, n, B, A * 3, A, out_path, n_fevals,
-                                      [&](const float* xs, float t, float* o) { painn_drift_dev(h, xs, t, cd, B, o); });
+                                      [&](const float* xs, float t, float* o, float*) { painn_drift_dev(h, xs, t, cd, B, o); });
         h->tap = saved_tap;
         return rc;
     });
@@ -647,47 +659,50 @@ ti_handle* ti_adw_create(const ti_adw_desc* d, const double* weights, size_t n_w
         const int H = d->hidden_size, nl = d->num_layers;
         if (H != 32 && H != 64 && H != 128 && H != 256) return fail(TI_E_UNSUPPORTED, "hidden_size must be 32, 64, 128 or 256");
         if (nl < 1) return fail(TI_E_ARG, "num_layers must be >= 1");
+        if (d->precision != TI_PREC_F32 && d->precision != TI_PREC_F16X2) return fail(TI_E_ARG, "unknown precision");
         const size_t need = (size_t)H * 3 + H + (size_t)H * H + H + H + 1 + (size_t)H * 3 + H + (size_t)(nl - 1) * ((size_t)H * H + H) + H + 1;
         if (n_weights != need) return fail(TI_E_ARG, "weight count mismatch: expected " + std::to_string(need) + ", got " + std::to_string(n_weights));
         std::unique_ptr<ti_handle> h(new_handle(1, device));
         h->ad = *d; h->NB = H / 32;
         std::vector<float> w(n_weights);
         for (size_t i = 0; i < n_weights; ++i) w[i] = (float)weights[i];        // the device computes in fp32
-        // natural-order vectors are repacked so every vector the kernel float4-loads is 16-byte aligned
+        const int NB = h->NB, NBK = H / 16;
+        const bool split = d->precision == TI_PREC_F16X2;
         std::vector<float> nat, pk;
-        auto push = [&](const float* p, size_t n) { size_t off = nat.size(); nat.insert(nat.end(), p, p + n); while (nat.size() % 4) nat.push_back(0.f); return off; };
+        auto chunk16 = [&](const float* W, int row0) {
+            if (split) pack_chunk16_split(pk, W, H, H, row0, 0, NBK); else pack_chunk16(pk, W, H, H, row0, 0, NBK);
+        };
+        // one MLP block: canonical order  W_in[H,3] b_in[H] (W_h[H,H] b_h[H]) x n_hidden  W_out[1,H] b_out[1]
+        auto take_mlp = [&](size_t& o, int n_hidden, size_t& vec_off, Stream& st, float& b_out) {
+            vec_off = nat.size();
+            nat.insert(nat.end(), &w[o], &w[o] + (size_t)H * 3); o += (size_t)H * 3;      // w_in
+            nat.insert(nat.end(), &w[o], &w[o] + H); o += H;                              // b_in
+            st.off4 = pk.size() / 4;
+            std::vector<float> bh;
+            for (int l = 0; l < n_hidden; ++l) {
+                for (int nbo = 0; nbo < NB; ++nbo) chunk16(&w[o], 32 * nbo);
+                o += (size_t)H * H;
+                bh.insert(bh.end(), &w[o], &w[o] + H); o += H;
+            }
+            st.nch = n_hidden * NB;
+            nat.insert(nat.end(), bh.begin(), bh.end());
+            nat.insert(nat.end(), &w[o], &w[o] + H); o += H;                              // w_out
+            b_out = w[o]; o += 1;
+        };
         size_t o = 0;
-        h->a_be_w_in = push(&w[o], (size_t)H * 3); o += (size_t)H * 3;
-        h->a_be_b_in = push(&w[o], H); o += H;
-        const size_t be_W1 = o; o += (size_t)H * H;
-        h->a_be_b_h = push(&w[o], H); o += H;
-        h->a_be_w_out = push(&w[o], H); o += H;
-        h->a_be_b_out = w[o]; o += 1;
-        h->a_w_in = push(&w[o], (size_t)H * 3); o += (size_t)H * 3;
-        h->a_b_in = push(&w[o], H); o += H;
-        std::vector<size_t> Wh; std::vector<float> bh;
-        for (int l = 1; l < nl; ++l) { Wh.push_back(o); o += (size_t)H * H; bh.insert(bh.end(), &w[o], &w[o] + H); o += H; }
-        if (bh.empty()) bh.assign(4, 0.f);
-        h->a_b_h = push(bh.data(), bh.size());
-        h->a_w_out = push(&w[o], H); o += H;
-        h->a_b_out = w[o]; o += 1;
-        const int NB = h->NB;
-        h->st_be.off4 = 0;
-        for (int nbo = 0; nbo < NB; ++nbo) pack_chunk(pk, &w[be_W1], H, H, 32 * nbo, 0, NB);
-        h->st_be.nch = NB;
-        h->st_net.off4 = pk.size() / 4;
-        for (size_t Wl : Wh) for (int nbo = 0; nbo < NB; ++nbo) pack_chunk(pk, &w[Wl], H, H, 32 * nbo, 0, NB);
-        h->st_net.nch = (int)Wh.size() * NB;
+        take_mlp(o, 1, h->a_be_vecs, h->st_be, h->a_be_b_out);
+        take_mlp(o, nl - 1, h->a_net_vecs, h->st_net, h->a_b_out);
         if (pk.empty()) pk.assign(4, 0.f);
         h->flat.upload(nat); h->packed.upload(pk);
-        HIP_CHECK(configure_adw_kernels(NB));
+        HIP_CHECK(configure_adw_kernels(NB, std::max(1, nl - 1)));
         out = h.release();
         return TI_OK;
     });
     return rc == TI_OK ? out : nullptr;
 }
 
-int ti_adw_drift(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out, int mem)
+static int adw_drift_impl(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out,
+                          float* out_div, int mem)
 {
     if (!h || h->kind != 1) return fail(TI_E_ARG, "not an adw handle");
     if (B < 0 || (B > 0 && (!x || !beta0 || !beta1 || !out))) return fail(TI_E_ARG, "NULL buffer");
@@ -696,17 +711,34 @@ int ti_adw_drift(ti_handle* h, const float* x, float t, const float* beta0, cons
         set_device(h);
         ensure_adw_ws(h, B);
         const long long U = adw_set_cond(h, beta0, beta1, B, mem);
-        const float* xd = x; float* od = out;
-        if (mem == TI_MEM_HOST) { HIP_CHECK(hipMemcpyAsync(h->ax.p, x, B * sizeof(float), hipMemcpyHostToDevice, h->stream)); xd = h->ax.p; od = h->ab1.p; }
-        adw_drift_dev(h, xd, t, U, B, od);
-        if (mem == TI_MEM_HOST) HIP_CHECK(hipMemcpyAsync(out, od, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        const float* xd = x; float* od = out; float* dd = out_div;
+        if (mem == TI_MEM_HOST) {
+            HIP_CHECK(hipMemcpyAsync(h->ax.p, x, B * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            xd = h->ax.p; od = h->ab1.p; dd = out_div ? h->ad1.p : nullptr;
+        }
+        adw_drift_dev(h, xd, t, U, B, od, dd);
+        if (mem == TI_MEM_HOST) {
+            HIP_CHECK(hipMemcpyAsync(out, od, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            if (out_div) HIP_CHECK(hipMemcpyAsync(out_div, dd, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        }
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return TI_OK;
     });
 }
 
-int ti_adw_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, const float* beta0, const float* beta1, int64_t B,
-                   float* out_path, int64_t* n_fevals)
+int ti_adw_drift(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out, int mem)
+{
+    return adw_drift_impl(h, x, t, beta0, beta1, B, out, nullptr, mem);
+}
+
+int ti_adw_drift_div(ti_handle* h, const float* x, float t, const float* beta0, const float* beta1, int64_t B, float* out, float* out_div, int mem)
+{
+    if (!out_div) return fail(TI_E_ARG, "out_div is NULL");
+    return adw_drift_impl(h, x, t, beta0, beta1, B, out, out_div, mem);
+}
+
+static int adw_rollout_impl(ti_handle* h, const ti_rollout_desc* rd, const float* x0, const float* beta0, const float* beta1, int64_t B,
+                            float* out_path, float* out_dlogp, int64_t* n_fevals)
 {
     if (!h || h->kind != 1) return fail(TI_E_ARG, "not an adw handle");
     if (int rc = check_rollout_desc(rd)) return rc;
@@ -718,9 +750,25 @@ int ti_adw_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, con
         const long long U = adw_set_cond(h, beta0, beta1, B, rd->mem);
         const hipMemcpyKind in_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         HIP_CHECK(hipMemcpyAsync(h->ax.p, x0, B * sizeof(float), in_kind, h->stream));
+        DlogpAux aux;
+        DevBuf<float> scaled_tmp;                    // dlogp * 1e2 staging for the saved rows
+        if (out_dlogp) { scaled_tmp.alloc(B); aux.dl = h->adl.p; aux.d1 = h->ad1.p; aux.d2 = h->ad2.p; aux.scaled = scaled_tmp.p; aux.out = out_dlogp; }
         return rollout_common(h, rd, h->ax.p, h->ab1.p, h->ab2.p, h->axt.p, (size_t)B, B, 1, 0, out_path, n_fevals,
-                              [&](const float* xs, float t, float* o) { adw_drift_dev(h, xs, t, U, B, o); });
+                              [&](const float* xs, float t, float* o, float* dv) { adw_drift_dev(h, xs, t, U, B, o, dv); }, aux);
     });
+}
+
+int ti_adw_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, const float* beta0, const float* beta1, int64_t B,
+                   float* out_path, int64_t* n_fevals)
+{
+    return adw_rollout_impl(h, rd, x0, beta0, beta1, B, out_path, nullptr, n_fevals);
+}
+
+int ti_adw_rollout_dlogp(ti_handle* h, const ti_rollout_desc* rd, const float* x0, const float* beta0, const float* beta1, int64_t B,
+                         float* out_path, float* out_dlogp, int64_t* n_fevals)
+{
+    if (!out_dlogp) return fail(TI_E_ARG, "out_dlogp is NULL");
+    return adw_rollout_impl(h, rd, x0, beta0, beta1, B, out_path, out_dlogp, n_fevals);
 }
 
 // --------------------------------------------------------------------------------------------------------- shared

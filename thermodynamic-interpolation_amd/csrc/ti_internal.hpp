@@ -78,23 +78,24 @@ hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
 // ---- adw (adw_kernels.hip).  One kernel evaluates  Linear(3->H), SiLU, [Linear(H->H), SiLU] x n_hidden, Linear(H->1)
 // on rows (a0, a1, a2):  a0 = x[r];  a1 = in1 ? in1[r] : t;  a2 = idx ? emb[idx[r]] : emb ? emb[r] : t.
 struct AdwParams {
-    const float4* stream; int nch;          // hidden layers, 32-output chunks, layer-major
-    const float *w_in, *b_in;               // [H][3], [H]
-    const float* b_hidden;                  // [n_hidden][H]
-    const float* w_out; float b_out;        // [H], scalar
+    const float4* stream; int nch;          // hidden layers, 32-output chunks (16-row format), layer-major
+    const float* vecs;                      // w_in [H][3] | b_in [H] | b_hidden [n_hidden][H] | w_out [H]
+    float b_out;
     int n_hidden; long long B;
     const float* x; const float* in1; const float* emb; const int32_t* idx;
     float t;
     float* out;
+    float* out_div;                         // non-NULL: also d out / d a0 (forward-mode tangent)
 };
-hipError_t launch_adw(int NB, const AdwParams& p, hipStream_t st);
-hipError_t configure_adw_kernels(int NB);
+hipError_t launch_adw(int NB, bool split, const AdwParams& p, hipStream_t st);
+hipError_t configure_adw_kernels(int NB, int max_hidden);
 
 // ---- integrator kernels (integrate_kernels.hip)
 hipError_t launch_axpy(float* y, const float* x, float a, const float* b, long long n, hipStream_t st);          // y = x + a*b
 hipError_t launch_heun(float* x, float hdt, const float* b1, const float* b2, long long n, hipStream_t st);      // x += hdt*(b1+b2)
 hipError_t launch_noise(float* x, float sigma, uint64_t seed, long long traj0, int step, long long B, int comps_per_traj,
                         int atoms_for_com /*0 = no COM removal*/, hipStream_t st);
+hipError_t launch_scale(float* y, const float* x, float a, long long n, hipStream_t st);                            // y = a*x
 hipError_t launch_selftest(float* out /*[64*16]*/, hipStream_t st);
 hipError_t launch_nan_check(const float* x, long long n, int* flag, hipStream_t st);
 

@@ -159,11 +159,13 @@ class PainnEngine(_Engine):
 
 
 class AdwEngine(_Engine):
-    """FCNetMultiBeta drift + fixed-step integrator for the 1-D double well."""
+    """FCNetMultiBeta drift (+ exact divergence) and fixed-step integrator for the 1-D double well."""
 
-    def __init__(self, hidden, num_layers, flat_weights_f64, device=0):
-        self.hidden, self.num_layers = int(hidden), int(num_layers)
-        self.desc = _lib.AdwDesc(self.hidden, self.num_layers)
+    def __init__(self, hidden, num_layers, flat_weights_f64, device=0, precision="f32"):
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        self.hidden, self.num_layers, self.precision = int(hidden), int(num_layers), precision
+        self.desc = _lib.AdwDesc(self.hidden, self.num_layers, _lib.PRECISIONS[precision])
         w = np.ascontiguousarray(flat_weights_f64, np.float64)
         self.device = int(device)
         self.h = _lib.lib().ti_adw_create(C.byref(self.desc), w.ctypes.data_as(C.POINTER(C.c_double)), w.size, self.device)
@@ -177,16 +179,25 @@ class AdwEngine(_Engine):
             raise ValueError("x, beta0 and beta1 must live in the same memory space")
         return flags.pop()
 
-    def drift(self, x, t, beta0, beta1, out=None):
+    def drift(self, x, t, beta0, beta1, out=None, return_div=False):
+        """b(x, t) [B]; with return_div also d b / d x (the 1-D divergence, reference scaling NOT applied)."""
         B = int(x.shape[0])
         dev = self._same_space(x, beta0, beta1)
         (xp, xk, _), (b0p, b0k, _), (b1p, b1k, _) = _lib.as_ptr(x), _lib.as_ptr(beta0), _lib.as_ptr(beta1)
         out = _alloc_like(x if dev else None, (B,)) if out is None else out
         op, _, _ = _lib.as_ptr(out)
-        _lib.check(_lib.lib().ti_adw_drift(self.h, xp, float(t), b0p, b1p, B, op, _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
-        return out
+        mem = _lib.MEM_DEVICE if dev else _lib.MEM_HOST
+        if not return_div:
+            _lib.check(_lib.lib().ti_adw_drift(self.h, xp, float(t), b0p, b1p, B, op, mem))
+            return out
+        div = _alloc_like(x if dev else None, (B,))
+        dp, _, _ = _lib.as_ptr(div)
+        _lib.check(_lib.lib().ti_adw_drift_div(self.h, xp, float(t), b0p, b1p, B, op, dp, mem))
+        return out, div
 
-    def rollout(self, x0, beta0, beta1, t_grid, scheme="euler", save_every=1, eps=0.0, seed=0, traj_offset=0, out=None):
+    def rollout(self, x0, beta0, beta1, t_grid, scheme="euler", save_every=1, eps=0.0, seed=0, traj_offset=0, out=None,
+                return_dlogp=False):
+        """(path [rows,B], n_fevals), or (path, dlogp [rows,B] (already * 1e2 like the reference), n_fevals)."""
         B = int(x0.shape[0])
         dev = self._same_space(x0, beta0, beta1)
         (xp, xk, _), (b0p, b0k, _), (b1p, b1k, _) = _lib.as_ptr(x0), _lib.as_ptr(beta0), _lib.as_ptr(beta1)
@@ -195,8 +206,13 @@ class AdwEngine(_Engine):
         out = _alloc_like(x0 if dev else None, (rows, B)) if out is None else out
         op, _, _ = _lib.as_ptr(out)
         nfe = C.c_int64(0)
-        _lib.check(_lib.lib().ti_adw_rollout(self.h, C.byref(rd), xp, b0p, b1p, B, op, C.byref(nfe)))
-        return out, nfe.value
+        if not return_dlogp:
+            _lib.check(_lib.lib().ti_adw_rollout(self.h, C.byref(rd), xp, b0p, b1p, B, op, C.byref(nfe)))
+            return out, nfe.value
+        dl = _alloc_like(x0 if dev else None, (rows, B))
+        dp, _, _ = _lib.as_ptr(dl)
+        _lib.check(_lib.lib().ti_adw_rollout_dlogp(self.h, C.byref(rd), xp, b0p, b1p, B, op, dp, C.byref(nfe)))
+        return out, dl, nfe.value
 
 
 def selftest(device: int = 0):

@@ -1,7 +1,7 @@
 """Drop-in mirror of the reference adw sampling API on top of libti_hip.so.
 
   FCNetMultiBeta      <- /root/reference/adw/thermo/models/simple.py:5-41
-  ODEWrapper          <- /root/reference/adw/thermo/models/ode_wrapper.py:11-52   (drift only; divergence is §8f-1)
+  ODEWrapper          <- /root/reference/adw/thermo/models/ode_wrapper.py:11-68   (drift and exact divergence)
   StandardIntegrator  <- /root/reference/adw/thermo/integrators.py:11-68
 
 Same class names, constructor arguments and return shapes; tensors in, tensors out (numpy also accepted).  The modules hold
@@ -28,6 +28,7 @@ class FCNetMultiBeta:
         # the reference initialises with torch's default Linear init; weights normally arrive via load_state_dict / torch.load
         self._sd = _syn.make_state_dict(self._spec, seed=0, dtype=np.float64)
         self._engine, self._device = None, 0
+        self.precision = "f32"                  # 'f16x2': split-fp16 matrix path; set before first use
         self.training = False
 
     # -- torch.nn.Module surface used by the sampling driver (adw/sample.py:39, :84-88)
@@ -74,7 +75,7 @@ class FCNetMultiBeta:
     def engine(self) -> _engine.AdwEngine:
         if self._engine is None:
             flat = _W.flatten_state_dict(self._sd, self._spec, dtype=np.float64)
-            self._engine = _engine.AdwEngine(self.hidden_size, self.num_layers, flat, device=self._device)
+            self._engine = _engine.AdwEngine(self.hidden_size, self.num_layers, flat, device=self._device, precision=self.precision)
         return self._engine
 
     def forward(self, x0s, xts, ts, beta0s, beta1s):
@@ -93,18 +94,24 @@ class FCNetMultiBeta:
 
 
 class ODEWrapper:
-    """Drift-only mirror of the reference wrapper: forward(t, states, x0s, beta0s, beta1s) -> b."""
+    """forward(t, states, x0s, beta0s, beta1s) -> b, or (b, -divergence) with return_dlogp
+    (divergence = d b / d x * 1e-2 like ode_wrapper.py:55-67; reverse_ode flips both signs)."""
 
     def __init__(self, b, return_dlogp=False, reverse_ode=False):
-        if return_dlogp:
-            C.dlogp_unsupported()
         self.b, self.return_dlogp, self.reverse_ode = b, return_dlogp, reverse_ode
 
     def forward(self, integration_time, states, x0s, beta0s, beta1s):
         xs = states[0] if isinstance(states, (tuple, list)) else states
         t = float(integration_time)
-        ts = np.full(C.to_numpy(xs).shape, t, np.float32)
-        return self.b.forward(x0s, xs, ts, beta0s, beta1s)
+        if not self.return_dlogp:
+            ts = np.full(C.to_numpy(xs).shape, t, np.float32)
+            return self.b.forward(x0s, xs, ts, beta0s, beta1s)
+        x = np.ascontiguousarray(C.to_numpy(xs, np.float32).reshape(-1))
+        b0 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta0s, np.float32).reshape(-1), x.shape))
+        b1 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta1s, np.float32).reshape(-1), x.shape))
+        b, div = self.b.engine().drift(x, t, b0, b1, return_div=True)
+        b, div = C.like(b.reshape(-1, 1), xs), C.like(div * np.float32(1e-2), xs)
+        return (b, -div) if not self.reverse_ode else (-b, div)
 
     __call__ = forward
 
@@ -114,16 +121,15 @@ class StandardIntegrator:
 
     ``method``: 'euler' | 'heun' | 'em' on the grid torch.linspace(start, end, n_step) (n_step - 1 steps).  Extra keyword
     arguments are build-defined: ``eps``/``seed`` (EM noise), ``save_every`` (1 keeps every grid point like the reference;
-    0 keeps the end state only).  With return_dlogp=False the reference evaluates ``None * 1e2`` and raises
-    (integrators.py:42,68); here dlogp is returned as None instead.
+    0 keeps the end state only).  With return_dlogp=True the second ODE state d(dlogp)/dt = -div * 1e-2 is integrated with the
+    same scheme and returned * 1e2 as [n_saved, B, 1], like the reference (integrators.py:38-68).  With return_dlogp=False the
+    reference evaluates ``None * 1e2`` and raises (integrators.py:42,68); here dlogp is returned as None instead.
     """
 
     def __init__(self, b, method: str = "dopri5", n_step: int = 100, atol: float = 1e-4, rtol: float = 1e-4, start: float = 0.0,
                  end: float = 1.0, return_dlogp=False, *, eps: float = 0.0, seed: int = 0, save_every: int = 1):
         self.method = C.check_method(method)
-        if return_dlogp:
-            C.dlogp_unsupported()
-        self.ode_wrapper = ODEWrapper(b, return_dlogp=False)
+        self.ode_wrapper = ODEWrapper(b, return_dlogp=return_dlogp)
         self.start, self.end, self.rtol, self.atol = start, end, rtol, atol
         self.n_step, self.return_dlogp = n_step, return_dlogp
         self.eps, self.seed, self.save_every = eps, seed, save_every
@@ -136,7 +142,9 @@ class StandardIntegrator:
         b0 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta0s, np.float32).reshape(-1), (B,)))
         b1 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta1s, np.float32).reshape(-1), (B,)))
         grid = _engine.time_grid(self.start, self.end, self.n_step)
-        path, self.n_fevals = self.ode_wrapper.b.engine().rollout(np.ascontiguousarray(x0[:, 0]), b0, b1, grid, scheme=self.method,
-                                                                  save_every=self.save_every, eps=self.eps, seed=self.seed,
-                                                                  traj_offset=traj_offset)
-        return C.like(path[:, :, None], x0s), None
+        res = self.ode_wrapper.b.engine().rollout(np.ascontiguousarray(x0[:, 0]), b0, b1, grid, scheme=self.method,
+                                                  save_every=self.save_every, eps=self.eps, seed=self.seed, traj_offset=traj_offset,
+                                                  return_dlogp=bool(self.return_dlogp))
+        self.n_fevals = res[-1]
+        dlogp = C.like(res[1][:, :, None], x0s) if self.return_dlogp else None
+        return C.like(res[0][:, :, None], x0s), dlogp

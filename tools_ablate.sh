@@ -6,6 +6,7 @@ mkdir -p gpurun_out
 cd thermodynamic-interpolation_amd/csrc
 for v in BASE "$@"; do
   flags=""; [ "$v" != "BASE" ] && flags=$(echo $v | sed 's/+/ -D/g; s/^/-D/')
+  case "$v" in FLAG:*) flags="${v#FLAG:}";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTI_DEV_NB4_ONLY $flags -c painn_kernels.hip -o /tmp/pk.o 2>/dev/null || { echo "$v: compile failed"; continue; }
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c ti_api.hip -o /tmp/api.o 2>/dev/null
   hipcc --offload-arch=gfx950 -shared -fPIC -o ../libti_hip.so /tmp/api.o /tmp/pk.o ../build/adw_kernels.o || continue
