@@ -74,11 +74,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     dist = None
+    # TI_BENCH_TEST_SHARED_GPU=1 (rehearsal on a one-GPU box only): every rank uses cuda:0 and the gather goes through gloo on
+    # host copies, so the rank / shard / gather logic of the N > 1 path can be exercised without N GPUs.  Never a measurement.
+    shared_gpu_test = bool(os.environ.get("TI_BENCH_TEST_SHARED_GPU"))
+    if shared_gpu_test:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the sampling path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -94,7 +102,8 @@ def main():
     cond = torch.from_numpy(syn.ambient_cond(B, A)).to(dev)
     out = torch.empty((1, B, A, 3), dtype=torch.float32, device=dev)
     grid = ti.engine.time_grid(0.0, 1.0, 1001)            # config 4: 1000-step grid; we time K of its steps
-    gathered = [torch.empty_like(out[0]) for _ in range(world)] if world > 1 else None
+    gdev = "cpu" if shared_gpu_test else dev
+    gathered = [torch.empty((B, A, 3), dtype=torch.float32, device=gdev) for _ in range(world)] if world > 1 else None
 
     def sync():
         if world > 1:
@@ -111,7 +120,7 @@ def main():
             eng.rollout(x0, cond, grid[first_step:first_step + k_steps + 1], scheme="em", eps=args.eps, seed=1234,
                         traj_offset=rank * B, save_every=0, out=out)
             if world > 1:
-                dist.all_gather(gathered, out[0])         # the only collective: final gather of the samples (RCCL)
+                dist.all_gather(gathered, out[0].cpu() if shared_gpu_test else out[0])   # the only collective: final gather (RCCL)
 
         if args.warmup > 0:
             run(args.warmup, 0)
@@ -123,7 +132,7 @@ def main():
         dt = time.perf_counter() - t0
         eng.profile(False)
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         prof = {k: eng.profile_read(k) for k in ("painn_edge", "painn_update", "painn_embed", "painn_readout")}
@@ -151,7 +160,7 @@ def main():
             "metric": "integration-steps/sec (whole node)", "value": value, "unit": "trajectory-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 state and accumulation; matrix products on fp16 MFMA with 2-way split fp32 operands (hi + 2^-11 lo, 3 products)" if split else "f32", "data": "synthetic",
-            "config": {"workload": "mdqm9 ambient sampler: 65536 molecules/GPU x 18 atoms (fully connected, 306 edges), cPaiNN F=128 L=5, "
+            "config": {"workload": f"mdqm9 ambient sampler: {B} molecules/GPU x 18 atoms (fully connected, 306 edges), cPaiNN F=128 L=5, "
                                    "Euler-Maruyama steps of the 1000-step grid, T1 over a 6-rung ladder",
                        "trajectories_per_gpu": B, "atoms": A, "n_features": F, "score_layers": L, "scheme": "em", "eps": args.eps,
                        "sharding": f"dp{world} over independent trajectories, final RCCL all-gather of end states"},

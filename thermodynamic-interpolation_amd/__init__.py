@@ -4,4 +4,4 @@ The directory name is fixed by the build contract and is not a Python identifier
 ``importlib.import_module("thermodynamic-interpolation_amd")`` (tests/conftest.py and __graft_entry__.py do).
 Importing the package never loads the HIP library; the first engine does, and fails loudly if it is missing.
 """
-from . import weights, synthetic, build, _lib, engine, thermo, distributed  # noqa: F401
+from . import weights, synthetic, build, _lib, engine, thermo, distributed, data, drivers  # noqa: F401

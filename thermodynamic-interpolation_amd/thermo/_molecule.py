@@ -63,6 +63,7 @@ class PaiNNShell:
         self._spec = _W.painn_param_spec(self.VARIANT, self.n_features, self.score_layers, self.n_types)
         self._sd = _syn.make_state_dict(self._spec, seed=0)       # placeholder init; real weights come from load_state_dict
         self._engines, self._device = {}, 0
+        self.precision = "f32"                  # 'f16x2': split-fp16 matrix path; set before first use
         self.training = False
 
     # -- torch.nn.Module surface used by the sampling drivers (sample_ambient.py:71-72,125-131)
@@ -93,12 +94,12 @@ class PaiNNShell:
         return iter(self._sd.values())
 
     def engine_for(self, A, src, dst, ety, atom_ids) -> _engine.PainnEngine:
-        key = (A, src.tobytes(), dst.tobytes(), ety.tobytes(), atom_ids.tobytes())
+        key = (A, src.tobytes(), dst.tobytes(), ety.tobytes(), atom_ids.tobytes(), self.precision)
         if key not in self._engines:
             flat = _W.flatten_state_dict(self._sd, self._spec)
             self._engines[key] = _engine.PainnEngine(self.VARIANT, self.n_features, self.score_layers, A, src, dst, ety, atom_ids, flat,
                                                      n_types=self.n_types, temp_length=self.temp_length, time_length=self.time_length,
-                                                     temperatures=self.temperatures, device=self._device)
+                                                     temperatures=self.temperatures, device=self._device, precision=self.precision)
         return self._engines[key]
 
     def cond_of(self, batch, B, A) -> np.ndarray | None:
