@@ -112,6 +112,51 @@ class PainnOracle:
             raise RuntimeError(f"tio_painn_drift rc={rc}")
         return (out, taps) if taps else out
 
+    def jvp(self, x, xdot, t, cond=None, precision=32, tap_stage=-1):
+        """(b(x), (db/dx) xdot); with tap_stage >= 0 also the TANGENTS of s, v, e after that stage."""
+        x, xdot = f32(x), f32(xdot)
+        B = x.shape[0]
+        cond = None if self.ncond == 0 else f32(cond)
+        out, tan = np.empty((B, self.A, 3), np.float32), np.empty((B, self.A, 3), np.float32)
+        taps = None
+        if tap_stage >= 0:
+            taps = dict(s=np.zeros((B, self.A, self.F), np.float32), v=np.zeros((B, self.A, self.F, 3), np.float32),
+                        e=np.zeros((B, self.E, self.F), np.float32))
+        rc = lib().tio_painn_jvp(C.c_void_p(self.h), precision, _p(x, C.c_float), _p(xdot, C.c_float), C.c_float(t), _p(cond, C.c_float),
+                                 C.c_int64(B), _p(out, C.c_float), _p(tan, C.c_float), tap_stage,
+                                 _p(taps["s"], C.c_float) if taps else None, _p(taps["v"], C.c_float) if taps else None,
+                                 _p(taps["e"], C.c_float) if taps else None)
+        if rc:
+            raise RuntimeError(f"tio_painn_jvp rc={rc}")
+        return (out, tan, taps) if taps else (out, tan)
+
+    def drift_div(self, x, t, cond=None, precision=32):
+        """(b(x) [B,A,3] f32, div [B] f64) with div = sum_ij d b_ij / d x_ij (no 1e-2 factor)."""
+        x = f32(x)
+        B = x.shape[0]
+        cond = None if self.ncond == 0 else f32(cond)
+        out, div = np.empty((B, self.A, 3), np.float32), np.empty(B, np.float64)
+        rc = lib().tio_painn_drift_div(C.c_void_p(self.h), precision, _p(x, C.c_float), C.c_float(t), _p(cond, C.c_float), C.c_int64(B),
+                                       _p(out, C.c_float), _p(div, C.c_double))
+        if rc:
+            raise RuntimeError(f"tio_painn_drift_div rc={rc}")
+        return out, div
+
+    def rollout_dlogp(self, x0, cond, t_grid, scheme="euler", save_every=1, precision=32, div_scale=1.0, reverse_ode=False):
+        """(path [rows,B,A,3], dlogp [rows,B]) -- the raw second state (ambient callers multiply by 1e2)."""
+        x0 = f32(x0)
+        B = x0.shape[0]
+        cond = None if self.ncond == 0 else f32(cond)
+        rd = make_rollout_desc(scheme, t_grid, save_every)
+        rows = rollout_rows(rd.n_step, save_every)
+        out, dl = np.empty((rows, B, self.A, 3), np.float32), np.empty((rows, B), np.float32)
+        nfe = C.c_int64(0)
+        rc = lib().tio_painn_rollout_dlogp(C.c_void_p(self.h), precision, C.byref(rd), _p(x0, C.c_float), _p(cond, C.c_float), C.c_int64(B),
+                                           C.c_float(div_scale), int(bool(reverse_ode)), _p(out, C.c_float), _p(dl, C.c_float), C.byref(nfe))
+        if rc:
+            raise RuntimeError(f"tio_painn_rollout_dlogp rc={rc}")
+        return out, dl, nfe.value
+
     def rollout(self, x0, cond, t_grid, scheme="euler", save_every=1, precision=32, **kw):
         x0 = f32(x0)
         B = x0.shape[0]

@@ -131,6 +131,63 @@ int tio_painn_drift(void* hv, int precision, const float* x, float t, const floa
     return painn_drift_f32(h->m32, h->src, h->dst, h->etype, h->atom_ids, x, t, cond, B, out, tap_stage, tap_s, tap_v, tap_e);
 }
 
+/* forward-mode derivative along xdot [B,A,3]; tangent taps like tio_painn_drift */
+int tio_painn_jvp(void* hv, int precision, const float* x, const float* xdot, float t, const float* cond, int64_t B, float* out,
+                  float* out_tan, int tap_stage, float* tap_s, float* tap_v, float* tap_e)
+{
+    tio_painn* h = hv;
+    if (precision == 64)
+        return painn_jvp_f64(h->m64, h->src, h->dst, h->etype, h->atom_ids, x, xdot, t, cond, B, out, out_tan, tap_stage, tap_s, tap_v, tap_e);
+    return painn_jvp_f32(h->m32, h->src, h->dst, h->etype, h->atom_ids, x, xdot, t, cond, B, out, out_tan, tap_stage, tap_s, tap_v, tap_e);
+}
+
+/* drift and exact divergence sum_ij d b_ij / d x_ij (ODEWrapper.compute_divergence without its 1e-2 factor) */
+int tio_painn_drift_div(void* hv, int precision, const float* x, float t, const float* cond, int64_t B, float* out, double* div)
+{
+    tio_painn* h = hv;
+    if (precision == 64) return painn_div_f64(h->m64, h->src, h->dst, h->etype, h->atom_ids, x, t, cond, B, out, div);
+    return painn_div_f32(h->m32, h->src, h->dst, h->etype, h->atom_ids, x, t, cond, B, out, div);
+}
+
+/* MoleculeIntegrator.rollout(return_dlogp=True) on a fixed grid (ambient/integrators.py:36-68, latent/integrators.py:57-89):
+ * states (x, dlogp), func = (b, -div_scale*div), or (-b, +div_scale*div) with reverse_ode (ode_wrapper.py:49; the grid is
+ * then linspace(end, start)); out_dlogp [rows,B] holds the raw second state -- the ambient caller multiplies by 1e2. */
+int tio_painn_rollout_dlogp(void* hv, int precision, const ti_rollout_desc* rd, const float* x0, const float* cond, int64_t B,
+                            float div_scale, int reverse_ode, float* out_path, float* out_dlogp, int64_t* n_fevals)
+{
+    tio_painn* h = hv;
+    const int A = h->d.n_atoms; const size_t n = (size_t)B * A * 3;
+    if (rd->scheme == TI_SCHEME_EM) return -1;
+    float *x = malloc(sizeof(float) * n), *b1 = malloc(sizeof(float) * n), *b2 = malloc(sizeof(float) * n), *xt = malloc(sizeof(float) * n);
+    float* dl = calloc((size_t)B, sizeof(float)); double *d1 = malloc(8 * (size_t)B), *d2 = malloc(8 * (size_t)B);
+    const float sb = reverse_ode ? -1.0f : 1.0f, sd = reverse_ode ? 1.0f : -1.0f;
+    memcpy(x, x0, sizeof(float) * n);
+    int64_t row = 0, fe = 0;
+#define SAVE_ROW() do { memcpy(out_dlogp + row * B, dl, sizeof(float) * (size_t)B); memcpy(out_path + (row++) * n, x, sizeof(float) * n); } while (0)
+    if (rd->save_every > 0) SAVE_ROW();
+    for (int k = 0; k < rd->n_step - 1; ++k) {
+        const float dt = rd->t_grid[k + 1] - rd->t_grid[k];
+        tio_painn_drift_div(hv, precision, x, rd->t_grid[k], cond, B, b1, d1); ++fe;
+        if (rd->scheme == TI_SCHEME_HEUN) {
+            for (size_t i = 0; i < n; ++i) xt[i] = x[i] + dt * (sb * b1[i]);
+            tio_painn_drift_div(hv, precision, xt, rd->t_grid[k + 1], cond, B, b2, d2); ++fe;
+            const float hdt = 0.5f * dt;
+            for (size_t i = 0; i < n; ++i) x[i] = x[i] + hdt * (sb * b1[i] + sb * b2[i]);
+            for (int64_t i = 0; i < B; ++i) dl[i] = dl[i] + hdt * (sd * ((float)d1[i] * div_scale) + sd * ((float)d2[i] * div_scale));
+        } else {
+            for (size_t i = 0; i < n; ++i) x[i] = x[i] + dt * (sb * b1[i]);
+            for (int64_t i = 0; i < B; ++i) dl[i] = dl[i] + dt * (sd * ((float)d1[i] * div_scale));
+        }
+        const int step = k + 1;
+        if (rd->save_every > 0 && (step % rd->save_every == 0 || step == rd->n_step - 1)) SAVE_ROW();
+    }
+    if (rd->save_every <= 0) SAVE_ROW();
+#undef SAVE_ROW
+    if (n_fevals) *n_fevals = fe;
+    free(x); free(b1); free(b2); free(xt); free(dl); free(d1); free(d2);
+    return 0;
+}
+
 /* Fixed-step rollout on grid t[0..n_step-1]; out_path [rows,B,A,3] as ti_painn_rollout. fp32 state like the reference. */
 int tio_painn_rollout(void* hv, int precision, const ti_rollout_desc* rd, const float* x0, const float* cond, int64_t B,
                       float* out_path, int64_t* n_fevals)

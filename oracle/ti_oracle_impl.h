@@ -289,6 +289,282 @@ static int FN(painn_drift)(const FN(painn_t)* m, const int* src, const int* dst,
     return fail ? -4 : 0;
 }
 
+/* ------------------------------------------------------------------------------------- forward-mode twin (JVP)
+ * The reference obtains the divergence with 3A reverse-mode passes over the same graph
+ * (ODEWrapper.compute_divergence, mdqm9/thermo/ambient/models/ode_wrapper.py:59-91: sum_ij d b_ij / d x_ij).  The
+ * restatement differentiates the forward pass above line by line in forward mode (one pass per seed direction); both
+ * give the exact derivative of the same arithmetic, the summation orders differ. */
+static void FN(ln_silu_jvp)(REAL* x, REAL* dx, int rows, int F, const REAL* g, const REAL* be)
+{
+    for (int r = 0; r < rows; ++r) {
+        REAL* xr = x + (size_t)r * F; REAL* dr = dx + (size_t)r * F;
+        REAL mean = 0, var = 0, dmean = 0, proj = 0;
+        for (int i = 0; i < F; ++i) { mean += xr[i]; dmean += dr[i]; }
+        mean /= (REAL)F; dmean /= (REAL)F;
+        for (int i = 0; i < F; ++i) { REAL d = xr[i] - mean; var += d * d; }
+        var /= (REAL)F;
+        const REAL rstd = (REAL)1 / RSQRT(var + (REAL)1e-5);
+        for (int i = 0; i < F; ++i) proj += (xr[i] - mean) * rstd * (dr[i] - dmean);
+        proj /= (REAL)F;
+        for (int i = 0; i < F; ++i) {
+            const REAL n = (xr[i] - mean) * rstd;
+            const REAL dn = rstd * ((dr[i] - dmean) - n * proj);
+            const REAL v = n * g[i] + be[i], dv = dn * g[i];
+            const REAL sg = (REAL)1 / ((REAL)1 + REXP(-v));
+            xr[i] = v * sg;
+            dr[i] = dv * sg * ((REAL)1 + v * ((REAL)1 - sg));
+        }
+    }
+}
+
+/* tmp: rows*f_h*4 scratch */
+static void FN(mlp_jvp)(const FN(mlp_t)* m, const REAL* x, const REAL* dx, int rows, REAL* y, REAL* dy, REAL* tmp)
+{
+    REAL* h1 = tmp; REAL* h2 = h1 + (size_t)rows * m->f_h; REAL* d1 = h2 + (size_t)rows * m->f_h; REAL* d2 = d1 + (size_t)rows * m->f_h;
+    FN(linear)(x, rows, m->f_in, m->f_in, m->W0t, m->b0, m->f_h, h1, m->f_h);
+    FN(linear)(dx, rows, m->f_in, m->f_in, m->W0t, NULL, m->f_h, d1, m->f_h);
+    FN(ln_silu_jvp)(h1, d1, rows, m->f_h, m->g0, m->be0);
+    FN(linear)(h1, rows, m->f_h, m->f_h, m->W1t, m->b1, m->f_h, h2, m->f_h);
+    FN(linear)(d1, rows, m->f_h, m->f_h, m->W1t, NULL, m->f_h, d2, m->f_h);
+    FN(ln_silu_jvp)(h2, d2, rows, m->f_h, m->g1, m->be1);
+    FN(linear)(h2, rows, m->f_h, m->f_h, m->W2t, m->b2, m->f_out, y, m->f_out);
+    FN(linear)(d2, rows, m->f_h, m->f_h, m->W2t, NULL, m->f_out, dy, m->f_out);
+}
+
+static void FN(posenc_jvp)(REAL x, REAL dx, REAL max_length, int F, REAL* out, REAL* dout)
+{
+    const REAL xs = x / max_length, dxs = dx / max_length;
+    for (int k = 1; k <= F / 2; ++k) {
+        const REAL a = (xs * (REAL)k) * (REAL)M_PI, da = (dxs * (REAL)k) * (REAL)M_PI;
+        const REAL c = RCOS(a), sn = RSIN(a);
+        out[2 * (k - 1)] = c;       dout[2 * (k - 1)] = -sn * da;
+        out[2 * (k - 1) + 1] = sn;  dout[2 * (k - 1) + 1] = c * da;
+    }
+}
+
+/* One molecule, one seed direction xdot [A][3]: out = b(x) [A][3], out_tan = (d b / d x) xdot [A][3].
+ * Tangent taps (may be NULL) after `tap_stage` as in painn_molecule: ds [A][F], dv [A][F][3], de [E][F]. */
+static void FN(painn_molecule_jvp)(const FN(painn_t)* m, const int* src, const int* dst, const int* etype, const int* atom_ids,
+                                   const float* x, const float* xdot, float t, const float* cond, float* out, float* out_tan,
+                                   REAL* out_tan_real, int tap_stage, float* tap_s, float* tap_v, float* tap_e, REAL* ws)
+{
+    const int F = m->d.n_features, L = m->d.n_layers, A = m->d.n_atoms, E = m->d.n_edges, nE = m->nE;
+    const size_t M = E > A ? E : A;
+#define TAKE(name, n) REAL* name = ws; ws += (size_t)(n); REAL* CAT(d_, name) = ws; ws += (size_t)(n)
+    TAKE(s, (size_t)A * F); TAKE(v, (size_t)A * F * 3); TAKE(e, (size_t)E * F); TAKE(dist, E); TAKE(dir, (size_t)E * 3);
+    TAKE(enc, (size_t)E * F); TAKE(big_in, M * (nE > 2 ? nE : 2) * F); TAKE(phi_o, (size_t)E * 5 * F); TAKE(w_o, (size_t)E * 5 * F);
+    TAKE(acc_s, (size_t)A * F); TAKE(acc_v, (size_t)A * F * 3); TAKE(vv, (size_t)A * F * 3); TAKE(uv, (size_t)A * F * 3);
+    TAKE(upd_o, (size_t)A * 3 * F);
+#undef TAKE
+    REAL* tmp = ws;               /* M * 4 * F */
+
+    for (int k = 0; k < E; ++k) {                                                   /* K1 */
+        REAL r[3], dr[3]; REAL n2 = 0, rd = 0;
+        for (int c = 0; c < 3; ++c) {
+            r[c] = (REAL)x[src[k] * 3 + c] - (REAL)x[dst[k] * 3 + c];
+            dr[c] = (REAL)xdot[src[k] * 3 + c] - (REAL)xdot[dst[k] * 3 + c];
+            n2 += r[c] * r[c]; rd += r[c] * dr[c];
+        }
+        dist[k] = RSQRT(n2);
+        d_dist[k] = dist[k] > 0 ? rd / dist[k] : 0;
+        const REAL q = (REAL)1 + dist[k];
+        for (int c = 0; c < 3; ++c) { dir[k * 3 + c] = r[c] / q; d_dir[k * 3 + c] = dr[c] / q - r[c] * d_dist[k] / (q * q); }
+    }
+    memset(v, 0, sizeof(REAL) * (size_t)A * F * 3); memset(d_v, 0, sizeof(REAL) * (size_t)A * F * 3);      /* K2 */
+    for (int k = 0; k < E; ++k) memcpy(e + (size_t)k * F, m->edge_emb + (size_t)etype[k] * F, sizeof(REAL) * F);   /* K3 */
+    memset(d_e, 0, sizeof(REAL) * (size_t)E * F);
+    for (int a = 0; a < A; ++a) {
+        REAL* row = big_in + (size_t)a * nE * F;
+        memcpy(row, m->atom_emb + (size_t)atom_ids[a] * F, sizeof(REAL) * F);
+        for (int c = 0; c < m->ncond; ++c) {
+            REAL u = (REAL)cond[a * m->ncond + c] - (REAL)m->d.temp_mean * (REAL)1;
+            u = u / (REAL)m->d.temp_range;
+            FN(posenc)(u, (REAL)m->d.temp_length, F, row + (size_t)(1 + c) * F);
+        }
+        FN(posenc)((REAL)t, (REAL)m->d.time_length, F, row + (size_t)(nE - 1) * F);
+    }
+    FN(mlp)(&m->embed, big_in, A, s, tmp);                                          /* K4: no dependence on x */
+    memset(d_s, 0, sizeof(REAL) * (size_t)A * F);
+#define TAPJ(stage) do { if (tap_stage == (stage)) { \
+        if (tap_s) for (size_t i = 0; i < (size_t)A * F; ++i) tap_s[i] = (float)d_s[i]; \
+        if (tap_v) for (size_t i = 0; i < (size_t)A * F * 3; ++i) tap_v[i] = (float)d_v[i]; \
+        if (tap_e) for (size_t i = 0; i < (size_t)E * F; ++i) tap_e[i] = (float)d_e[i]; } } while (0)
+    TAPJ(0);
+    for (int k = 0; k < E; ++k) FN(posenc_jvp)(dist[k], d_dist[k], (REAL)m->d.length_scale, F, enc + (size_t)k * F, d_enc + (size_t)k * F);
+
+    for (int l = 0; l < L; ++l) {
+        for (int k = 0; k < E; ++k) {                                               /* K5 */
+            memcpy(big_in + (size_t)k * 2 * F, s + (size_t)src[k] * F, sizeof(REAL) * F);
+            memcpy(big_in + (size_t)k * 2 * F + F, e + (size_t)k * F, sizeof(REAL) * F);
+            memcpy(d_big_in + (size_t)k * 2 * F, d_s + (size_t)src[k] * F, sizeof(REAL) * F);
+            memcpy(d_big_in + (size_t)k * 2 * F + F, d_e + (size_t)k * F, sizeof(REAL) * F);
+        }
+        FN(mlp_jvp)(&m->phi[l], big_in, d_big_in, E, phi_o, d_phi_o, tmp);
+        FN(mlp_jvp)(&m->w[l], enc, d_enc, E, w_o, d_w_o, tmp);
+        memset(acc_s, 0, sizeof(REAL) * (size_t)A * F); memset(d_acc_s, 0, sizeof(REAL) * (size_t)A * F);
+        memset(acc_v, 0, sizeof(REAL) * (size_t)A * F * 3); memset(d_acc_v, 0, sizeof(REAL) * (size_t)A * F * 3);
+        for (int k = 0; k < E; ++k) {
+            const REAL* h = phi_o + (size_t)k * 5 * F; const REAL* g = w_o + (size_t)k * 5 * F;
+            const REAL* dh = d_phi_o + (size_t)k * 5 * F; const REAL* dg = d_w_o + (size_t)k * 5 * F;
+            const REAL* d3 = dir + k * 3; const REAL* dd3 = d_dir + k * 3;
+            const REAL* vs = v + (size_t)src[k] * F * 3; const REAL* dvs = d_v + (size_t)src[k] * F * 3;
+            const REAL* vd = v + (size_t)dst[k] * F * 3; const REAL* dvd = d_v + (size_t)dst[k] * F * 3;
+            for (int f = 0; f < F; ++f) {
+#define PROD(i) h[(i) * F + f] * g[(i) * F + f]
+#define DPROD(i) (dh[(i) * F + f] * g[(i) * F + f] + h[(i) * F + f] * dg[(i) * F + f])
+                const REAL gate = PROD(0), sed = PROD(1), dsf = PROD(2), def = PROD(3), cg = PROD(4);
+                const REAL dgate = DPROD(0), dsed = DPROD(1), ddsf = DPROD(2), ddef = DPROD(3), dcg = DPROD(4);
+#undef PROD
+#undef DPROD
+                const REAL b[3] = { vd[f * 3], vd[f * 3 + 1], vd[f * 3 + 2] }, db[3] = { dvd[f * 3], dvd[f * 3 + 1], dvd[f * 3 + 2] };
+                const REAL cr[3] = { d3[1] * b[2] - d3[2] * b[1], d3[2] * b[0] - d3[0] * b[2], d3[0] * b[1] - d3[1] * b[0] };
+                const REAL dcr[3] = { dd3[1] * b[2] + d3[1] * db[2] - dd3[2] * b[1] - d3[2] * db[1],
+                                      dd3[2] * b[0] + d3[2] * db[0] - dd3[0] * b[2] - d3[0] * db[2],
+                                      dd3[0] * b[1] + d3[0] * db[1] - dd3[1] * b[0] - d3[1] * db[0] };
+                for (int c = 0; c < 3; ++c) {
+                    acc_v[((size_t)dst[k] * F + f) * 3 + c] += (sed * d3[c] + gate * vs[f * 3 + c]) + cg * cr[c];
+                    d_acc_v[((size_t)dst[k] * F + f) * 3 + c] += (dsed * d3[c] + sed * dd3[c] + dgate * vs[f * 3 + c] + gate * dvs[f * 3 + c])
+                                                               + (dcg * cr[c] + cg * dcr[c]);
+                }
+                acc_s[(size_t)dst[k] * F + f] += dsf; d_acc_s[(size_t)dst[k] * F + f] += ddsf;
+                phi_o[(size_t)k * 5 * F + 3 * F + f] = def; d_phi_o[(size_t)k * 5 * F + 3 * F + f] = ddef;
+            }
+        }
+        for (size_t i = 0; i < (size_t)A * F * 3; ++i) { v[i] += acc_v[i]; d_v[i] += d_acc_v[i]; }
+        for (size_t i = 0; i < (size_t)A * F; ++i) { s[i] += acc_s[i]; d_s[i] += d_acc_s[i]; }
+        for (int k = 0; k < E; ++k) for (int f = 0; f < F; ++f) {
+            e[(size_t)k * F + f] += phi_o[(size_t)k * 5 * F + 3 * F + f]; d_e[(size_t)k * F + f] += d_phi_o[(size_t)k * 5 * F + 3 * F + f];
+        }
+        TAPJ(1 + 2 * l);
+
+        for (int a = 0; a < A; ++a) {                                               /* K7 */
+            for (int c = 0; c < 3; ++c) {
+                for (int o = 0; o < F; ++o) {
+                    const size_t i = ((size_t)a * F + o) * 3 + c; vv[i] = 0; uv[i] = 0; d_vv[i] = 0; d_uv[i] = 0;
+                }
+                for (int k = 0; k < F; ++k) {
+                    const REAL a_in = v[((size_t)a * F + k) * 3 + c], da_in = d_v[((size_t)a * F + k) * 3 + c];
+                    const REAL* wv = m->Vt[l] + (size_t)k * F; const REAL* wu = m->Ut[l] + (size_t)k * F;
+                    for (int o = 0; o < F; ++o) {
+                        const size_t i = ((size_t)a * F + o) * 3 + c;
+                        vv[i] += a_in * wv[o]; uv[i] += a_in * wu[o]; d_vv[i] += da_in * wv[o]; d_uv[i] += da_in * wu[o];
+                    }
+                }
+            }
+            REAL* row = big_in + (size_t)a * 2 * F; REAL* drow = d_big_in + (size_t)a * 2 * F;
+            for (int f = 0; f < F; ++f) {
+                const REAL* q = vv + ((size_t)a * F + f) * 3; const REAL* dq = d_vv + ((size_t)a * F + f) * 3;
+                row[f] = RSQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                drow[f] = row[f] > 0 ? (q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2]) / row[f] : 0;   /* torch: d|q| = 0 at q = 0 */
+                row[F + f] = s[(size_t)a * F + f]; drow[F + f] = d_s[(size_t)a * F + f];
+            }
+        }
+        FN(mlp_jvp)(&m->upd[l], big_in, d_big_in, A, upd_o, d_upd_o, tmp);
+        for (int a = 0; a < A; ++a) for (int f = 0; f < F; ++f) {
+            const size_t o = (size_t)a * 3 * F;
+            const REAL gate = upd_o[o + f], ssn = upd_o[o + F + f], add = upd_o[o + 2 * F + f];
+            const REAL dgate = d_upd_o[o + f], dssn = d_upd_o[o + F + f], dadd = d_upd_o[o + 2 * F + f];
+            const REAL n = big_in[(size_t)a * 2 * F + f], dn = d_big_in[(size_t)a * 2 * F + f];
+            s[(size_t)a * F + f] += (n * n) * ssn + add;
+            d_s[(size_t)a * F + f] += ((REAL)2 * n * dn) * ssn + (n * n) * dssn + dadd;
+            for (int c = 0; c < 3; ++c) {
+                const size_t i = ((size_t)a * F + f) * 3 + c;
+                v[i] += uv[i] * gate; d_v[i] += d_uv[i] * gate + uv[i] * dgate;
+            }
+        }
+        TAPJ(2 + 2 * l);
+    }
+    FN(mlp_jvp)(&m->readout, s, d_s, A, upd_o, d_upd_o, tmp);                       /* K8 */
+    for (int a = 0; a < A; ++a) {
+        const REAL gate = upd_o[a * 2 + 1], dgate = d_upd_o[a * 2 + 1];
+        for (int c = 0; c < 3; ++c) {
+            REAL acc = 0, dacc = 0;
+            for (int f = 0; f < F; ++f) { acc += v[((size_t)a * F + f) * 3 + c] * m->Vr[f]; dacc += d_v[((size_t)a * F + f) * 3 + c] * m->Vr[f]; }
+            out[a * 3 + c] = (float)(acc * gate);
+            out_tan[a * 3 + c] = (float)(dacc * gate + acc * dgate);
+            if (out_tan_real) out_tan_real[a * 3 + c] = dacc * gate + acc * dgate;
+        }
+    }
+#undef TAPJ
+}
+
+static size_t FN(painn_jvp_ws_size)(const FN(painn_t)* m)
+{
+    const size_t F = m->d.n_features, A = m->d.n_atoms, E = m->d.n_edges, nE = m->nE, M = E > A ? E : A;
+    return 2 * (A * F + A * F * 3 + E * F + E + E * 3 + E * F + M * (nE > 2 ? nE : 2) * F + 2 * E * 5 * F + A * F + 3 * (A * F * 3) + A * 3 * F)
+         + M * 4 * F + 64;
+}
+
+/* xdot [B][A][3] -> out, out_tan [B][A][3] */
+static int FN(painn_jvp)(const FN(painn_t)* m, const int* src, const int* dst, const int* etype, const int* atom_ids,
+                         const float* x, const float* xdot, float t, const float* cond, long B, float* out, float* out_tan,
+                         int tap_stage, float* tap_s, float* tap_v, float* tap_e)
+{
+    const int A = m->d.n_atoms, F = m->d.n_features, E = m->d.n_edges;
+    const size_t wsn = FN(painn_jvp_ws_size)(m);
+    int fail = 0;
+#pragma omp parallel
+    {
+        REAL* ws = (REAL*)malloc(sizeof(REAL) * wsn);
+        if (!ws) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (long b = 0; b < B; ++b)
+                FN(painn_molecule_jvp)(m, src, dst, etype, atom_ids, x + (size_t)b * A * 3, xdot + (size_t)b * A * 3, t,
+                                       cond ? cond + (size_t)b * A * m->ncond : NULL, out + (size_t)b * A * 3, out_tan + (size_t)b * A * 3,
+                                       NULL, tap_stage, tap_s ? tap_s + (size_t)b * A * F : NULL, tap_v ? tap_v + (size_t)b * A * F * 3 : NULL,
+                                       tap_e ? tap_e + (size_t)b * E * F : NULL, ws);
+            free(ws);
+        }
+    }
+    return fail ? -4 : 0;
+}
+
+/* out [B][A][3] = b(x); div [B] = sum_{a,c} d b[a][c] / d x[a][c]  (3A unit seeds per molecule; the diagonal entries are
+ * summed in (a, c) order like the reference's double loop, ode_wrapper.py:80-84; no 1e-2 factor here).  div is returned
+ * as double so that the REAL = double build keeps its digits; the REAL = float build accumulates in float like torch. */
+static int FN(painn_div)(const FN(painn_t)* m, const int* src, const int* dst, const int* etype, const int* atom_ids,
+                         const float* x, float t, const float* cond, long B, float* out, double* div)
+{
+    const int A = m->d.n_atoms, D = 3 * A;
+    const size_t wsn = FN(painn_jvp_ws_size)(m);
+    REAL* diag = (REAL*)malloc(sizeof(REAL) * (size_t)B * D);
+    int fail = diag ? 0 : 1;
+    if (!fail) {
+#pragma omp parallel
+        {
+            REAL* ws = (REAL*)malloc(sizeof(REAL) * wsn);
+            float* seed = (float*)calloc((size_t)D, sizeof(float)); float* tan = (float*)malloc(sizeof(float) * 2 * D);
+            REAL* tan_real = (REAL*)malloc(sizeof(REAL) * D);
+            if (!ws || !seed || !tan || !tan_real) {
+#pragma omp atomic write
+                fail = 1;
+            } else {
+#pragma omp for schedule(dynamic, 1)
+                for (long job = 0; job < B * D; ++job) {
+                    const long b = job / D; const int k = (int)(job % D);
+                    seed[k] = 1.0f;
+                    FN(painn_molecule_jvp)(m, src, dst, etype, atom_ids, x + (size_t)b * D, seed, t, cond ? cond + (size_t)b * A * m->ncond : NULL,
+                                           tan + D, tan, tan_real, -1, NULL, NULL, NULL, ws);
+                    seed[k] = 0.0f;
+                    diag[job] = tan_real[k];
+                    if (k == 0) memcpy(out + (size_t)b * D, tan + D, sizeof(float) * D);
+                }
+            }
+            free(ws); free(seed); free(tan); free(tan_real);
+        }
+        for (long b = 0; b < B && !fail; ++b) {
+            REAL acc = 0;
+            for (int k = 0; k < D; ++k) acc += diag[(size_t)b * D + k];
+            div[b] = (double)acc;
+        }
+    }
+    free(diag);
+    return fail ? -4 : 0;
+}
+
 /* ------------------------------------------------------------------------------------------------------------ adw */
 typedef struct { int H, nl; REAL *be_W0t, *be_b0, *be_W1t, *be_b1, *be_W2, *be_b2; REAL **Wt, **b; REAL* store; } FN(adw_t);
 

@@ -60,6 +60,10 @@ def install_shims():
             if k in self.__dict__:
                 object.__delattr__(self, k)
 
+        def to_data_list(self):              # compute_divergence only reads the per-molecule x / x0 shapes (ode_wrapper.py:74)
+            n = int(self.batch.max()) + 1
+            return [Batch(**{k: getattr(self, k)[self.batch == i] for k in ("x", "x0") if hasattr(self, k)}) for i in range(n)]
+
     tgd.Batch = Batch
     tgd.Data = Batch
     tg.data = tgd
@@ -277,10 +281,76 @@ def adw_case(name, hidden, layers, B, *, seed, ctor_init=False, traj_steps=11):
     print(f"{name}: |b|={np.linalg.norm(out['drift_0']):.5f}  size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KiB")
 
 
+def painn_div_case(name, variant, F, L, A, B, template, temp_length, temperatures, *, seed, t=0.25, traj_steps=4, sigma=0.3,
+                   atom_ids=None):
+    """Exact divergence / dlogp fixtures: the reference ODEWrapper with return_dlogp=True evaluated at (x, t)
+    -> (b, -div * scale) in fp32 like the reference (the reference modules do not run in fp64: AddEquivariantFeatures
+    allocates float32, so the rounding-noise yardstick is the oracle's fp64 build); plus hand-rolled Euler / Heun loops over the two-state wrapper, forward and (latent) reverse_ode."""
+    src, dst, etype = template
+    atom_ids = np.arange(A, dtype=np.int32) if atom_ids is None else np.asarray(atom_ids, np.int32)
+    x = syn.molecule_coords(B, A, seed=seed, sigma=sigma)
+    if variant == W.AMBIENT:
+        cond = syn.ambient_cond(B, A)
+    elif variant == W.LATENT_MULTI:
+        cond = np.asarray([800.0, 300.0, 1000.0, 500.0], np.float32)[np.arange(B) % 4][:, None, None] * np.ones((B, A, 1), np.float32)
+    else:
+        cond = np.zeros((B, A, 0), np.float32)
+    out = dict(variant=variant, F=F, L=L, A=A, B=B, seed=seed, temp_length=float(temp_length),
+               temperatures=np.asarray(temperatures, np.float32), time_length=10.0, length_scale=10.0,
+               edge_src=src, edge_dst=dst, edge_type=etype, atom_ids=atom_ids, x=x, cond=cond, t=np.float32(t),
+               div_scale=np.float32(1e-2 if variant == W.AMBIENT else 1.0))
+    model = build_model(variant, F, L, temp_length, temperatures, syn.painn_state_dict(variant, F, L, 25, seed))
+    Ode = AmbientODE if variant == W.AMBIENT else LatentODE
+    batch = make_batch(variant, x, cond, src, dst, etype, atom_ids)
+
+    def call(ode, tt, xs, dl):
+        args = (torch.tensor(tt, dtype=xs.dtype), (xs, dl), batch) + (([0],) if variant == W.AMBIENT else ())
+        r = ode(*args)
+        return r[0].detach(), r[1].detach()
+
+    ode = Ode(model, return_dlogp=True)
+    b, negdiv = call(ode, float(t), batch.x0.clone(), torch.zeros(B))
+    out["drift"], out["negdiv_scaled"] = b.numpy().reshape(B, A, 3).copy(), negdiv.numpy().copy()
+    # two-state fixed-step loops (forward; reverse_ode for the latent wrapper, whose reverse branch returns a 2-tuple)
+    for reverse in ((False, True) if variant != W.AMBIENT else (False,)):
+        ode_r = Ode(model, return_dlogp=True, reverse_ode=reverse)
+        grid = torch.linspace(1.0, 0.0, traj_steps) if reverse else torch.linspace(0.0, 1.0, traj_steps)
+        for scheme in ("euler", "heun"):
+            xs, dl = batch.x0.clone(), torch.zeros(B)
+            path, dls = [xs.numpy().copy()], [dl.numpy().copy()]
+            for k in range(traj_steps - 1):
+                dt = grid[k + 1] - grid[k]
+                f1, g1 = call(ode_r, float(grid[k]), xs, dl)
+                if scheme == "euler":
+                    xs, dl = xs + dt * f1, dl + dt * g1
+                else:
+                    f2, g2 = call(ode_r, float(grid[k + 1]), xs + dt * f1, dl + dt * g1)
+                    xs, dl = xs + (0.5 * dt) * (f1 + f2), dl + (0.5 * dt) * (g1 + g2)
+                path.append(xs.numpy().copy()); dls.append(dl.numpy().copy())
+            tag = f"{scheme}{'_rev' if reverse else ''}"
+            out[f"traj_{tag}"] = np.stack(path).reshape(traj_steps, B, A, 3)
+            out[f"dlogp_{tag}"] = np.stack(dls)
+            out[f"grid{'_rev' if reverse else ''}"] = grid.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: negdiv_scaled={out['negdiv_scaled']}  size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KiB")
+
+
+def div_cases():
+    fc = syn.fully_connected_template
+    painn_div_case("div_ambient_small", W.AMBIENT, 32, 2, 5, 3, fc(5), 100, TEMPS, seed=1)
+    painn_div_case("div_ambient_sparse", W.AMBIENT, 32, 2, 7, 2, syn.sparse_template(7, seed=3), 100, TEMPS, seed=2, atom_ids=[3, 0, 6, 24, 1, 1, 9])
+    painn_div_case("div_ambient_f128", W.AMBIENT, 128, 3, 6, 2, fc(6), 100, TEMPS, seed=11, traj_steps=3)
+    painn_div_case("div_latent_multi", W.LATENT_MULTI, 32, 2, 6, 2, fc(6), 75, TEMPS, seed=7, sigma=1.0)
+    painn_div_case("div_latent_single", W.LATENT_SINGLE, 64, 2, 4, 2, fc(4), 75, [800], seed=8, sigma=1.0)
+
+
 TEMPS = [300, 400, 500, 600, 700, 800, 900, 1000]
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "--div-only" in sys.argv:      # only the divergence fixtures (the drift fixtures above are unchanged by them)
+        div_cases()
+        sys.exit(0)
     fc = syn.fully_connected_template
     # --- ambient (mdqm9/thermo/ambient)
     painn_case("ambient_small", W.AMBIENT, 32, 2, 5, 3, fc(5), 100, TEMPS, seed=1, intermediates=True, traj_steps=6)
@@ -299,3 +369,4 @@ if __name__ == "__main__":
     # --- adw (adw/thermo)
     adw_case("adw_h256", 256, 5, 64, seed=0)
     adw_case("adw_ctor_h64", 64, 3, 16, seed=1, ctor_init=True)
+    div_cases()

@@ -162,6 +162,30 @@ def test_painn_large_batch_properties():
     assert rel_l2(b[idx], orc.drift(x[idx], 0.5, cond[idx])) < DRIFT_TOL
 
 
+def test_painn_race_screen_full_occupancy():
+    """Every CU holds two workgroups and workgroups are replaced mid-launch (1366 workgroups, 512 resident): the weight
+    stream's LDS-DMA / barrier protocol is exercised under memory load, where an early fragment read shows up as a few
+    wrong molecules per launch (seen during development at ~1 in 4096; invisible at the small parity sizes).  The f32 and
+    split-fp16 builds are independent instruction streams, so per-molecule agreement of repeated launches of both is the
+    screen; the absolute check against the oracle is the small-batch parity tests' job."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    F, L, A, B = 128, 5, 18, 16384
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=0), W.painn_param_spec(0, F, L, 25))
+    x, cond = syn.molecule_coords(B, A, seed=0), syn.ambient_cond(B, A)
+    outs = []
+    for prec in ("f32", "f16x2"):
+        eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision=prec)
+        outs += [eng.drift(x, 0.5, cond).reshape(B, -1) for _ in range(3)]
+        eng.close()
+    ref = outs[0]
+    scale = np.linalg.norm(ref, axis=1)
+    for o in outs[1:]:
+        per_mol = np.linalg.norm(o - ref, axis=1) / scale
+        assert per_mol.max() < 3e-5, f"{(per_mol >= 3e-5).sum()} molecules disagree, worst {per_mol.max():.2e}"
+
+
 # ----------------------------------------------------------------------------------------------------------- adw
 def adw_engine(g):
     ti = pkg()

@@ -117,3 +117,56 @@ def test_adw_divergence_matches_reference_autograd(name):
     for tag in ("", "_var"):
         b, div = o.drift_div(g["x"].astype(np.float64), 0.3, g["beta0" + tag], g["beta1" + tag])   # the generator used t = 0.3 (fp64)
         assert rel_l2(-div * 1e-2, g[f"negdiv{tag}_1"].ravel()) < 1e-10
+
+
+# ------------------------------------------------------------------------------- mdqm9 exact divergence
+DIV_CASES = ["div_ambient_small", "div_ambient_sparse", "div_ambient_f128", "div_latent_multi", "div_latent_single"]
+# Tolerance for the divergence: the trace is a sum of 3A Jacobian entries of either sign, so rounding noise is measured
+# against sum_k |J_kk| ~ the per-direction magnitudes, not against the (possibly cancelling) trace.  Stated bar: the fp32
+# oracle and the fp32 reference autograd agree to 2e-5 * (|div| + 1) absolute on the unscaled divergence; the fp64 oracle
+# shows what part of that is the reference's own round-off.
+DIV_ATOL = 2e-5
+
+
+@pytest.mark.parametrize("name", DIV_CASES)
+def test_painn_divergence_matches_reference_autograd(name):
+    g = load_golden(name)
+    o = make_oracle(g)
+    scale = float(g["div_scale"])
+    ref_div = -g["negdiv_scaled"].astype(np.float64) / scale              # undo (b, -div * scale) of the wrapper
+    b32, d32 = o.drift_div(g["x"], float(g["t"]), g["cond"], precision=32)
+    b64, d64 = o.drift_div(g["x"], float(g["t"]), g["cond"], precision=64)
+    assert rel_l2(b32, g["drift"]) < TOL_BAR and rel_l2(b64, g["drift"]) < TOL_BAR
+    bar = DIV_ATOL * (np.abs(ref_div) + 1.0)
+    assert (np.abs(d64 - ref_div) < bar).all(), (name, d64, ref_div)
+    assert (np.abs(d32 - ref_div) < bar).all(), (name, d32, ref_div)
+    # forward mode along an arbitrary direction agrees with a central difference of the fp64 drift
+    rs = np.random.RandomState(3)
+    h = np.float32(2.0 ** -11)
+    xp = (g["x"] + h * rs.standard_normal(g["x"].shape)).astype(np.float32)
+    xm = (2.0 * g["x"].astype(np.float64) - xp).astype(np.float32)
+    xdot = ((xp.astype(np.float64) - xm) / (2.0 * float(h))).astype(np.float32)     # exact: the direction actually stepped in fp32
+    _, tan = o.jvp(g["x"], xdot, float(g["t"]), g["cond"], precision=64)
+    fd = (o.drift(xp, float(g["t"]), g["cond"], precision=64).astype(np.float64) - o.drift(xm, float(g["t"]), g["cond"], precision=64)) / (2.0 * float(h))
+    assert rel_l2(tan, fd) < 1e-3              # O(h^2) truncation + fp32 storage of the drift (6e-8 / h)
+
+
+@pytest.mark.parametrize("name", DIV_CASES)
+@pytest.mark.parametrize("scheme", ["euler", "heun"])
+def test_painn_dlogp_trajectory(name, scheme):
+    """Two-state fixed-step loops over the reference ODEWrapper(return_dlogp=True): forward, and reverse_ode (latent)."""
+    g = load_golden(name)
+    o = make_oracle(g)
+    scale = float(g["div_scale"])
+    for rev in ([False, True] if "grid_rev" in g else [False]):
+        tag = scheme + ("_rev" if rev else "")
+        grid = g["grid_rev" if rev else "grid"]
+        path, dl, nfe = o.rollout_dlogp(g["x"], g["cond"], grid, scheme=scheme, div_scale=scale, reverse_ode=rev)
+        ref, ref_dl = g[f"traj_{tag}"], g[f"dlogp_{tag}"]
+        assert path.shape == ref.shape and dl.shape == ref_dl.shape
+        assert nfe == (len(grid) - 1) * (2 if scheme == "heun" else 1)
+        assert rel_l2(path - path[0], ref - ref[0]) < 5e-6
+        assert (np.abs(dl - ref_dl) < DIV_ATOL * scale * (np.abs(ref_dl) / scale + 1.0)).all(), (name, tag, dl, ref_dl)
+        last, dl_last, _ = o.rollout_dlogp(g["x"], g["cond"], grid, scheme=scheme, save_every=0, div_scale=scale, reverse_ode=rev)
+        np.testing.assert_array_equal(last[0], path[-1])
+        np.testing.assert_array_equal(dl_last[0], dl[-1])
