@@ -133,6 +133,22 @@ int ti_painn_drift(ti_handle* h, const float* x, float t, const float* cond, int
 int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* cond, int64_t B,
                      float* out_path, int64_t* n_fevals);
 
+/* Forward-mode derivative of the drift along xdot [B,A,3]: out = b(x), out_tan = (d b / d x) xdot.  The building block
+ * of the divergence below; also what the parity tests tap stage by stage. */
+int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t, const float* cond, int64_t B, float* out,
+                       float* out_tan, int mem);
+/* Exact divergence out_div[b] = sum_{a,c} d b[b,a,c] / d x[b,a,c] by 3A unit-seed forward-mode passes per molecule --
+ * what ODEWrapper.compute_divergence obtains with 3A reverse-mode passes (mdqm9/thermo/ambient/models/ode_wrapper.py:59-91,
+ * latent/models/ode_wrapper.py:57-86), WITHOUT the ambient wrapper's 1e-2 factor.  Tangent state is processed in chunks of
+ * molecules sized to TI_JVP_WS_GB gigabytes of HBM (environment, default 48). */
+int ti_painn_drift_div(ti_handle* h, const float* x, float t, const float* cond, int64_t B, float* out, float* out_div, int mem);
+/* MoleculeIntegrator.rollout(return_dlogp=True) (ambient/integrators.py:36-68, latent/integrators.py:57-89) on the fixed
+ * grid of `desc` (EULER or HEUN; EM is refused): second state d(dlogp)/dt = -div_scale * div, or with reverse_ode the pair
+ * (-b, +div_scale * div) (ode_wrapper.py:49; the caller passes the descending grid linspace(end, start)).
+ * out_dlogp [rows, B] = state * out_scale.  Reference values: ambient div_scale 1e-2, out_scale 1e2; latent 1, 1. */
+int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* cond, int64_t B,
+                           float div_scale, float out_scale, int reverse_ode, float* out_path, float* out_dlogp, int64_t* n_fevals);
+
 /* ---- shared ------------------------------------------------------------------------------------------------------ */
 void ti_destroy(ti_handle* h);
 /* Run on an external HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream); NULL restores the
@@ -142,11 +158,13 @@ int ti_set_stream(ti_handle* h, void* hip_stream);
 int ti_reserve(ti_handle* h, int64_t B);
 /* Live kernel timing with HIP events on the handle's stream (bench.py roofline leg). */
 enum { TI_KERNEL_PAINN_EDGE = 0, TI_KERNEL_PAINN_UPDATE = 1, TI_KERNEL_PAINN_EMBED = 2, TI_KERNEL_PAINN_READOUT = 3,
-       TI_KERNEL_ADW = 4, TI_KERNEL_INTEGRATE = 5, TI_KERNEL_COUNT = 6 };
+       TI_KERNEL_ADW = 4, TI_KERNEL_INTEGRATE = 5, TI_KERNEL_PAINN_JVP_EDGE = 6, TI_KERNEL_PAINN_JVP_UPDATE = 7,
+       TI_KERNEL_PAINN_JVP_READOUT = 8, TI_KERNEL_COUNT = 9 };
 int ti_profile_enable(ti_handle* h, int on);
 int ti_profile_read(ti_handle* h, int kernel, int64_t* n_launches, double* total_ms);   /* also resets that slot */
-/* Debug taps for parity tests: copy an intermediate of the LAST ti_painn_drift call to host.
- * what: 0 = s [B,A,F], 1 = v [B,A,3,F] (component-major planes), 2 = e (row-major [B,E_m,F], edges in (dst,src) order). */
+/* Debug taps for parity tests: copy an intermediate of the LAST ti_painn_drift / ti_painn_drift_jvp call to host.
+ * what: 0 = s [B,A,F], 1 = v [B,A,3,F] (component-major planes), 2 = e (row-major [B,E_m,F], edges in (dst,src) order);
+ * 3, 4, 5 = the tangents of s, v, e of the last ti_painn_drift_jvp call, same shapes. */
 int ti_painn_debug_tap(ti_handle* h, int stop_after_stage);   /* stage = 0 embed, 1+2l message l, 2+2l update l; -1 = off */
 int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats);
 /* Device self-test of the MFMA operand/accumulator lane maps the kernels rely on. */

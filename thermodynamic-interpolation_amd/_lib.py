@@ -17,13 +17,14 @@ TI_OK, TI_E_ARG, TI_E_HIP, TI_E_NAN, TI_E_ALLOC, TI_E_UNSUPPORTED = 0, -1, -2, -
 MEM_HOST, MEM_DEVICE = 0, 1
 SCHEMES = {"euler": 0, "heun": 1, "em": 2}
 PRECISIONS = {"f32": 0, "f16x2": 1}
-KERNELS = {"painn_edge": 0, "painn_update": 1, "painn_embed": 2, "painn_readout": 3, "adw": 4, "integrate": 5}
+KERNELS = {"painn_edge": 0, "painn_update": 1, "painn_embed": 2, "painn_readout": 3, "adw": 4, "integrate": 5,
+           "painn_jvp_edge": 6, "painn_jvp_update": 7, "painn_jvp_readout": 8}
 
 # every symbol include/ti_hip.h declares (tests/test_abi.py checks the library exports exactly these)
 ABI_SYMBOLS = [
     "ti_rollout_rows", "ti_version", "ti_device_count", "ti_last_error",
     "ti_adw_create", "ti_adw_drift", "ti_adw_drift_div", "ti_adw_rollout", "ti_adw_rollout_dlogp",
-    "ti_painn_create", "ti_painn_drift", "ti_painn_rollout",
+    "ti_painn_create", "ti_painn_drift", "ti_painn_rollout", "ti_painn_drift_jvp", "ti_painn_drift_div", "ti_painn_rollout_dlogp",
     "ti_destroy", "ti_set_stream", "ti_reserve", "ti_profile_enable", "ti_profile_read",
     "ti_painn_debug_tap", "ti_painn_debug_read", "ti_selftest",
 ]
@@ -89,6 +90,9 @@ def lib():
     L.ti_painn_create.argtypes = [C.POINTER(PainnDesc), fp, C.c_size_t, ip, ip, ip, ip, C.c_int]
     L.ti_painn_drift.argtypes = [vp, vp, C.c_float, vp, C.c_int64, vp, C.c_int]
     L.ti_painn_rollout.argtypes = [vp, C.POINTER(RolloutDesc), vp, vp, C.c_int64, vp, C.POINTER(C.c_int64)]
+    L.ti_painn_drift_jvp.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int64, vp, vp, C.c_int]
+    L.ti_painn_drift_div.argtypes = [vp, vp, C.c_float, vp, C.c_int64, vp, vp, C.c_int]
+    L.ti_painn_rollout_dlogp.argtypes = [vp, C.POINTER(RolloutDesc), vp, vp, C.c_int64, C.c_float, C.c_float, C.c_int, vp, vp, C.POINTER(C.c_int64)]
     L.ti_adw_create.restype = vp
     L.ti_adw_create.argtypes = [C.POINTER(AdwDesc), C.POINTER(C.c_double), C.c_size_t, C.c_int]
     L.ti_adw_drift.argtypes = [vp, vp, C.c_float, vp, vp, C.c_int64, vp, C.c_int]

@@ -424,6 +424,67 @@ __device__ __forceinline__ void posenc_set(Act<NBK>& a, float x_over_len, int q)
 }
 
 
+// ---- forward-mode (dual number) twins: the primal result is bit-identical to ln_silu / posenc_set above
+// LayerNorm + SiLU of a row and of its tangent:  n = (h - mean) rstd,  dn = rstd ((dh - mean(dh)) - n mean(n (dh - mean(dh)))),
+// y = n g + b,  silu'(y) = sig(y) (1 + y (1 - sig(y))).
+template <int NBK>
+__device__ __forceinline__ void ln_silu_dual(Act<NBK>& a, Act<NBK>& da, const float* gamma, const float* beta, int q)
+{
+    constexpr float invF = 1.0f / (16.0f * NBK);
+    float sum = 0.f, dsum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        sum += (a.b[nb].x + a.b[nb].y) + (a.b[nb].z + a.b[nb].w);
+        dsum += (da.b[nb].x + da.b[nb].y) + (da.b[nb].z + da.b[nb].w);
+    }
+    const float mean = xquarters(sum) * invF, dmean = xquarters(dsum) * invF;
+    float var = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = a.b[nb][r] - mean;
+            var = fmaf(d, d, var);
+        }
+    const float rstd = 1.0f / sqrtf(xquarters(var) * invF + 1e-5f);
+    float pr = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr = fmaf((a.b[nb][r] - mean) * rstd, da.b[nb][r] - dmean, pr);
+    const float proj = xquarters(pr) * invF;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const f32x4 gm = load_block(gamma, nb, q), bt = load_block(beta, nb, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float n = (a.b[nb][r] - mean) * rstd;
+            const float dn = rstd * ((da.b[nb][r] - dmean) - n * proj);
+            const float y = fmaf(n, gm[r], bt[r]);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+            a.b[nb][r] = y * sg;
+            da.b[nb][r] = (dn * gm[r]) * (sg * fmaf(y, 1.0f - sg, 1.0f));
+        }
+    }
+}
+
+// posenc_set and its derivative along dx_over_len:  d cos(a) = -sin(a) da,  d sin(a) = cos(a) da,  da = (dx_over_len k) pi
+template <int NBK>
+__device__ __forceinline__ void posenc_dual(Act<NBK>& a, Act<NBK>& da, float x_over_len, float dx_over_len, int q)
+{
+    constexpr float PI_F = 3.14159265358979323846f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const int m = 4 * nb + q;
+        float s1, c1, s2, c2;
+        sincos_cw((x_over_len * (float)(2 * m + 1)) * PI_F, s1, c1);
+        sincos_cw((x_over_len * (float)(2 * m + 2)) * PI_F, s2, c2);
+        const float d1 = (dx_over_len * (float)(2 * m + 1)) * PI_F, d2 = (dx_over_len * (float)(2 * m + 2)) * PI_F;
+        a.b[nb] = f32x4{c1, s1, c2, s2};
+        da.b[nb] = f32x4{-s1 * d1, c1 * d1, -s2 * d2, c2 * d2};
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Split-fp16 operands for the fp16 matrix rate (16x the f32 MFMA rate) at fp32-like accuracy.
 //   x = xh + 2^-11 * xl,   xh = fp16(x),  xl = fp16((x - xh) * 2^11)          (|x| < 65504)

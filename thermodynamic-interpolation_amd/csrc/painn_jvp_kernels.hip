@@ -1,0 +1,703 @@
+// painn_jvp_kernels.hip -- forward-mode derivative of the cPaiNN drift for gfx950 (MI355X): the exact divergence the
+// reference obtains with 3A reverse-mode passes (ODEWrapper.compute_divergence,
+// /root/reference/mdqm9/thermo/ambient/models/ode_wrapper.py:59-91; latent twin ode_wrapper.py:57-86).
+//
+// A "virtual molecule" vm = b * D + d is molecule b differentiated along seed direction d.  D = 3A with unit seeds
+// (d perturbs atom d / 3, component d % 3) gives the Jacobian diagonal, D = 1 with an explicit xdot an arbitrary JVP.
+// The kernels here carry ONLY tangents in HBM (ts, tv, te, tP and the three accumulators, laid out like their primal
+// twins but over virtual molecules).  Primal state is read from the ordinary drift pipeline, which the host runs in
+// lock step (ti_api.hip: tangent edge -> primal edge -> tangent update -> primal update per layer), and the primal
+// activations a tangent needs (LayerNorm statistics, SiLU slopes, gate values) are recomputed in registers next to it:
+// every matrix product below runs on (activation, tangent) pairs against the same weight chunk in LDS.
+//
+// Tangent rules restated from the forward pass (painn_kernels.hip; reference lines there):
+//   geometry  r = x_s - x_d, d = |r|, dir = r / (1 + d):   dd = r.dr / d,  ddir = dr / (1 + d) - r dd / (1 + d)^2
+//   products  (h g)' = h' g + h g' ;  cross(k, v)' = cross(k', v) + cross(k, v')
+//   norm      n = |V v|:  n' = (V v).(V v') / n   (0 at n = 0, like torch.norm's backward)
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "mfma_chain.hpp"
+#include "ti_internal.hpp"
+
+namespace ti {
+
+namespace {
+
+struct EV {          // same vector block as painn_kernels.hip (struct EV)
+    static constexpr int W_B0 = 0, W_G0 = 1, W_BE0 = 2, W_B1 = 3, W_G1 = 4, W_BE1 = 5, P_G0 = 6, P_BE0 = 7, P_B1 = 8, P_G1 = 9,
+                         P_BE1 = 10, P_B2 = 11, W_B2 = 16, COUNT = 21;
+};
+struct UV {          // same vector block as painn_kernels.hip (struct UV)
+    static constexpr int B0 = 0, G0 = 1, BE0 = 2, B1 = 3, G1 = 4, BE1 = 5, B2 = 6, PB0 = 9, COUNT = 10;
+};
+struct RV {          // readout vector block: b0 g0 be0 b1 g1 be1 w2_gate Vr
+    static constexpr int B0 = 0, G0 = 1, BE0 = 2, B1 = 3, G1 = 4, BE1 = 5, W2G = 6, VR = 7, COUNT = 8;
+};
+
+__device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+#define Z4 (f32x4{0.f, 0.f, 0.f, 0.f})
+
+}  // namespace
+
+// ================================================================================================== tangent edge kernel
+template <int NBK, bool SPLIT>
+__global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgeParams p)
+{
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    float* scratch = reinterpret_cast<float*>(lds + 4 * CH4) + wave * 128;         // [16 rows][8]: edge_dir, 0, its tangent, 0
+    float* vec = reinterpret_cast<float*>(lds + 4 * CH4) + WAVES * 128;            // [EV::COUNT][F]
+    for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
+        reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
+    PipeDMA<NB, T, 2> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+
+    const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
+    const bool group_ok = gi_raw < p.n_groups;
+    const long long gi = group_ok ? gi_raw : p.n_groups - 1;
+    const bool first = p.first != 0, last = p.last != 0;
+
+    for (int blk = 0; blk < p.nblk; ++blk) {
+        // ---- geometry of this lane's row and its tangent
+        const uint32_t meta = p.rows[blk * 16 + j];
+        long long vm = gi * p.G + row_mol(meta);
+        vm = vm < p.VB ? vm : p.VB - 1;
+        const long long pm = vm / p.D;
+        const int dsel = (int)(vm - pm * p.D);
+        const long long nsrc = pm * p.A + row_src(meta), ndst = pm * p.A + row_dst(meta);
+        const int ke = (meta & ROW_VALID) ? blk * 16 + j - row_mol(meta) * p.E : 0;   // sorted edge position inside the molecule
+        const size_t perow = ((size_t)(pm / p.G) * p.nblk) * 16 + (size_t)(pm % p.G) * p.E + ke;   // primal e row
+        const size_t terow0 = ((size_t)gi * p.nblk + blk) * 16;                       // tangent e rows of this block
+        float dist, ddist;
+        {
+            const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
+            const float ry = p.x[nsrc * 3 + 1] - p.x[ndst * 3 + 1];
+            const float rz = p.x[nsrc * 3 + 2] - p.x[ndst * 3 + 2];
+            float tx, ty, tz;
+            if (p.xdot) {
+                tx = p.xdot[nsrc * 3 + 0] - p.xdot[ndst * 3 + 0];
+                ty = p.xdot[nsrc * 3 + 1] - p.xdot[ndst * 3 + 1];
+                tz = p.xdot[nsrc * 3 + 2] - p.xdot[ndst * 3 + 2];
+            } else {                                                // unit seed on (atom, component) = (dsel / 3, dsel % 3)
+                const int sa = dsel / 3, sc = dsel - 3 * sa;
+                const float sg = (float)((row_src(meta) == sa) - (row_dst(meta) == sa));
+                tx = sc == 0 ? sg : 0.f; ty = sc == 1 ? sg : 0.f; tz = sc == 2 ? sg : 0.f;
+            }
+            dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            ddist = dist > 0.f ? (rx * tx + ry * ty + rz * tz) / dist : 0.f;
+            const float den = 1.0f + dist, k = ddist / (den * den);
+            if (q == 0) {
+                *reinterpret_cast<f32x4*>(scratch + j * 8) = f32x4{rx / den, ry / den, rz / den, 0.f};
+                *reinterpret_cast<f32x4*>(scratch + j * 8 + 4) = f32x4{tx / den - rx * k, ty / den - ry * k, tz / den - rz * k, 0.f};
+            }
+        }
+        // ---- w(enc(d)) hidden layers, activation and tangent
+        OP g2, tg2;
+        {
+            A16 t1, u1;
+            {
+                OP enc, tenc;
+                {
+                    A16 t, u;
+                    r16::posenc_dual(t, u, dist / p.length_scale, ddist / p.length_scale, q);
+                    enc.set(t); tenc.set(u);
+                }
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
+                    f32x4 b0 = Z4, b1 = Z4;
+                    r16::gemm_bt(a0, a1, enc, wl, lane);
+                    r16::gemm_bt(b0, b1, tenc, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    pipe.release();
+                }
+            }
+            r16::ln_silu_dual(t1, u1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
+            {
+                OP g1, tg1;
+                g1.set(t1); tg1.set(u1);
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
+                    f32x4 b0 = Z4, b1 = Z4;
+                    r16::gemm_bt(a0, a1, g1, wl, lane);
+                    r16::gemm_bt(b0, b1, tg1, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    pipe.release();
+                }
+            }
+            r16::ln_silu_dual(t1, u1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
+            g2.set(t1); tg2.set(u1);
+        }
+        // ---- phi([s[src] | e]) hidden layers
+        OP h2, th2;
+        {
+            A16 t1, u1;
+            {
+                OP ein, tein;
+                if (first) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
+                else       r16::load_set(t1, p.e + perow * F, q);
+                ein.set(t1);
+                if (first) {
+#pragma unroll
+                    for (int nb = 0; nb < NBK; ++nb) u1.b[nb] = Z4;
+                } else r16::load_set(u1, p.te + (terow0 + j) * F, q);
+                tein.set(u1);
+                const float* prow = p.P + (size_t)nsrc * F;
+                const float* tprow = p.tP + (size_t)(vm * p.A + row_src(meta)) * F;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
+                    f32x4 b0 = r16::load_block(tprow, 2 * c, q), b1 = r16::load_block(tprow, 2 * c + 1, q);
+                    r16::gemm_bt(a0, a1, ein, wl, lane);
+                    r16::gemm_bt(b0, b1, tein, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    pipe.release();
+                }
+            }
+            r16::ln_silu_dual(t1, u1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
+            {
+                OP h1, th1;
+                h1.set(t1); th1.set(u1);
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
+                    f32x4 b0 = Z4, b1 = Z4;
+                    r16::gemm_bt(a0, a1, h1, wl, lane);
+                    r16::gemm_bt(b0, b1, th1, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    pipe.release();
+                }
+            }
+            r16::ln_silu_dual(t1, u1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
+            h2.set(t1); th2.set(u1);
+        }
+        // ---- output layer, flipped (features on lanes, the block's rows 4q + r in registers); see painn_edge_kernel
+        uint32_t mi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mi[r] = p.rows[blk * 16 + 4 * q + r];
+        f32x4 sel;
+        int snode[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sel[r] = (row_slot(mi[r]) == j) ? 1.0f : 0.0f;
+            const int sn = p.slotnode[blk * 16 + 4 * q + r];
+            const long long m2 = gi * p.G + (sn >> 8);
+            snode[r] = (sn >= 0 && group_ok && m2 < p.VB) ? (int)(m2 * p.A + (sn & 255)) : -1;     // TANGENT node
+        }
+        // value and tangent of (phi_c + b)(w_c + b) for output chunk c, 32 features as two 16-feature blocks
+        auto out_pair = [&](int c, int nbo, f32x4& r0, f32x4& r1, f32x4& d0, f32x4& d1) {
+            f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4, ta0 = Z4, ta1 = Z4, tb0 = Z4, tb1 = Z4;
+            const f32x4* wl0 = pipe.acquire();
+            r16::gemm_fl(a0, a1, h2, wl0, lane);
+            r16::gemm_fl(ta0, ta1, th2, wl0, lane);
+            pipe.release();
+            const f32x4* wl1 = pipe.acquire();
+            r16::gemm_fl(b0, b1, g2, wl1, lane);
+            r16::gemm_fl(tb0, tb1, tg2, wl1, lane);
+            pipe.release();
+            const float* bp = vec + (EV::P_B2 + c) * F + 32 * nbo + j;
+            const float* bw = vec + (EV::W_B2 + c) * F + 32 * nbo + j;
+            const f32x4 A0 = a0 + bp[0], B0 = b0 + bw[0], A1 = a1 + bp[16], B1 = b1 + bw[16];
+            r0 = A0 * B0; r1 = A1 * B1;
+            d0 = ta0 * B0 + A0 * tb0; d1 = ta1 * B1 + A1 * tb1;
+        };
+        auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
+            f32x4 s0 = Z4, s1 = Z4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s0 = r16::mfma16(sel[r], v0[r], s0); s1 = r16::mfma16(sel[r], v1[r], s1); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (snode[r] >= 0) { float* d = dst + (size_t)snode[r] * stride; add_noret(d, s0[r]); add_noret(d + 16, s1[r]); }
+        };
+
+#pragma unroll 1
+        for (int nbo = 0; nbo < NB; ++nbo) {
+            const int fo = 32 * nbo + j;
+            {   // ds
+                f32x4 v0, v1, d0, d1;
+                out_pair(2, nbo, v0, v1, d0, d1);
+                emit(d0, d1, p.tdsacc + fo, F);
+            }
+            if (!last) {   // de
+                f32x4 v0, v1, d0, d1;
+                out_pair(3, nbo, v0, v1, d0, d1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* ep = p.te + (terow0 + 4 * q + r) * F + fo;
+                    if (group_ok) {
+                        if (first) { ep[0] = d0[r]; ep[16] = d1[r]; }
+                        else { add_noret(ep, d0[r]); add_noret(ep + 16, d1[r]); }
+                    }
+                }
+            }
+            {   // equivariant message
+                f32x4 sed0, sed1, tsed0, tsed1, gt0 = Z4, gt1 = Z4, tgt0 = Z4, tgt1 = Z4;
+                out_pair(1, nbo, sed0, sed1, tsed0, tsed1);
+                f32x4 vs[3][2], tvs[3][2];
+                if (!first) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        long long m2 = gi * p.G + row_mol(mi[r]);
+                        m2 = m2 < p.VB ? m2 : p.VB - 1;
+                        const long long pm2 = m2 / p.D;
+                        const float* vp = p.v + (size_t)(pm2 * p.A + row_src(mi[r])) * 3 * F + fo;
+                        const float* tp = p.tv + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16];
+                            tvs[c][0][r] = tp[c * F]; tvs[c][1][r] = tp[c * F + 16];
+                        }
+                    }
+                    out_pair(0, nbo, gt0, gt1, tgt0, tgt1);
+                }
+                f32x4 dir[4], tdir[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 8);
+                    tdir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 8 + 4);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    f32x4 v0, v1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v0[r] = tsed0[r] * dir[r][c] + sed0[r] * tdir[r][c];
+                        v1[r] = tsed1[r] * dir[r][c] + sed1[r] * tdir[r][c];
+                        if (!first) {
+                            v0[r] += tgt0[r] * vs[c][0][r] + gt0[r] * tvs[c][0][r];
+                            v1[r] += tgt1[r] * vs[c][1][r] + gt1[r] * tvs[c][1][r];
+                        }
+                    }
+                    emit(v0, v1, p.tdvacc + c * F + fo, 3 * F);
+                }
+                if (!first) {
+                    f32x4 cg0, cg1, tcg0, tcg1;
+                    out_pair(4, nbo, cg0, cg1, tcg0, tcg1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        f32x4 v0, v1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v0[r] = tcg0[r] * dir[r][c] + cg0[r] * tdir[r][c];
+                            v1[r] = tcg1[r] * dir[r][c] + cg1[r] * tdir[r][c];
+                        }
+                        emit(v0, v1, p.tcacc + c * F + fo, 3 * F);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================== tangent update kernel
+// Runs BEFORE the primal update kernel of the same layer: reads the primal s, v and the three primal accumulators as the
+// edge kernel left them (read only) and advances ts, tv, tP; the tangent accumulators are consumed and zeroed.
+template <int NBK, bool SPLIT>
+__global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdateParams p)
+{
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    float* vec = reinterpret_cast<float*>(lds + 4 * CH4);
+    for (int i = threadIdx.x; i < UV::COUNT * F / 4; i += T)
+        reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
+    PipeDMA<NB, T, 2> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+
+    const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;      // virtual node
+    const bool ok = node < p.N;
+    const long long nd = ok ? node : p.N - 1;
+    const long long vm = nd / p.A, pm = vm / p.D;
+    const size_t pn = (size_t)(pm * p.A + (nd - vm * p.A));                          // primal node
+    const float *vb = p.v + pn * 3 * F, *db = p.dvacc + pn * 3 * F, *cb = p.cacc + pn * 3 * F, *sb = p.s + pn * F, *ab = p.dsacc + pn * F;
+    float *tvb = p.tv + (size_t)nd * 3 * F, *tdb = p.tdvacc + (size_t)nd * 3 * F, *tcb = p.tcacc + (size_t)nd * 3 * F;
+    float *tsb = p.ts + (size_t)nd * F, *tab = p.tdsacc + (size_t)nd * F;
+
+    // v_eff = v + dvacc + cacc x v and its tangent for component c, one 16-feature block
+    auto veff = [&](int c, int nb, f32x4& val, f32x4& tan) {
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        const f32x4 vc = r16::load_block(vb + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
+        const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
+        const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
+        val = (vc + dd) + (k1 * v2 - k2 * v1);
+        const f32x4 tvc = r16::load_block(tvb + c * F, nb, q), tdd = r16::load_block(tdb + c * F, nb, q);
+        const f32x4 tv1 = r16::load_block(tvb + c1 * F, nb, q), tv2 = r16::load_block(tvb + c2 * F, nb, q);
+        const f32x4 tk1 = r16::load_block(tcb + c1 * F, nb, q), tk2 = r16::load_block(tcb + c2 * F, nb, q);
+        tan = (tvc + tdd) + ((tk1 * v2 + k1 * tv2) - (tk2 * v1 + k2 * tv1));
+    };
+
+    // ---- phase A: n2 = |V v_eff|^2, nd2 = (V v_eff).(V tv_eff); tv_eff is parked in tdvacc.  One spatial component at a
+    // time (the tangent stream repeats the V chunks per component): two live operand sets instead of six.
+    A16 n2, nd2;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) { n2.b[nb] = Z4; nd2.b[nb] = Z4; }
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        OP ve, tve;
+        {
+            A16 t, u;
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) veff(c, nb, t.b[nb], u.b[nb]);
+            ve.set(t); tve.set(u);
+            // park tv_eff[c] in tdvacc[c]: of the tangent accumulators only tdvacc[c] itself fed this component
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) if (ok) r16::store_block(tdb + c * F, nb, q, u.b[nb]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4;
+            r16::gemm_bt(a0, a1, ve, wl, lane);
+            r16::gemm_bt(b0, b1, tve, wl, lane);
+            n2.b[2 * ch] += a0 * a0; n2.b[2 * ch + 1] += a1 * a1;
+            nd2.b[2 * ch] += a0 * b0; nd2.b[2 * ch + 1] += a1 * b1;
+            pipe.release();
+        }
+    }
+    // |vv| and its tangent, in place: n2 <- n, nd2 <- n'
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float n = sqrtf(n2.b[nb][r]);
+            nd2.b[nb][r] = n > 0.f ? nd2.b[nb][r] / n : 0.f;
+            n2.b[nb][r] = n;
+        }
+    // ---- phase B: MLP([ |vv| , s + ds ])
+    OP h2, th2;
+    {
+        A16 t, u;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) { t.b[nb] = r16::load_block(vec + UV::B0 * F, nb, q); u.b[nb] = Z4; }
+        {
+            OP nn, tnn;
+            nn.set(n2); tnn.set(nd2);
+#pragma unroll
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], nn, wl, lane);
+                r16::gemm_bt(u.b[2 * ch], u.b[2 * ch + 1], tnn, wl, lane);
+                pipe.release();
+            }
+        }
+        {
+            OP ss, tss;
+            {
+                A16 x, y;
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb) {
+                    x.b[nb] = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);
+                    y.b[nb] = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
+                }
+                ss.set(x); tss.set(y);
+            }
+#pragma unroll
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], ss, wl, lane);
+                r16::gemm_bt(u.b[2 * ch], u.b[2 * ch + 1], tss, wl, lane);
+                pipe.release();
+            }
+        }
+        r16::ln_silu_dual(t, u, vec + UV::G0 * F, vec + UV::BE0 * F, q);
+        {
+            OP h1, th1;
+            h1.set(t); th1.set(u);
+#pragma unroll
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                f32x4 a0 = r16::load_block(vec + UV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B1 * F, 2 * ch + 1, q);
+                f32x4 b0 = Z4, b1 = Z4;
+                r16::gemm_bt(a0, a1, h1, wl, lane);
+                r16::gemm_bt(b0, b1, th1, wl, lane);
+                t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
+                pipe.release();
+            }
+        }
+        r16::ln_silu_dual(t, u, vec + UV::G1 * F, vec + UV::BE1 * F, q);
+        h2.set(t); th2.set(u);
+    }
+    // ---- output chunks: [scale_squared_norm, add_invariant] per 32-feature block, then gates
+#pragma unroll
+    for (int ch = 0; ch < NB; ++ch) {
+        const f32x4* wl = pipe.acquire();
+        f32x4 q0 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch, q), q1 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch + 1, q);
+        f32x4 tq0 = Z4, tq1 = Z4;
+        r16::gemm_bt(q0, q1, h2, wl, lane);
+        r16::gemm_bt(tq0, tq1, th2, wl, lane);
+        pipe.release();
+        wl = pipe.acquire();
+        f32x4 ta0 = Z4, ta1 = Z4;                      // the primal `add` term does not enter any tangent
+        r16::gemm_bt(ta0, ta1, th2, wl, lane);
+        pipe.release();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int nb = 2 * ch + k;
+            f32x4 so = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
+            const f32x4 qq = k ? q1 : q0, tqq = k ? tq1 : tq0, taa = k ? ta1 : ta0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float n = n2.b[nb][r], dn = nd2.b[nb][r];
+                so[r] = so[r] + (((2.0f * n) * dn) * qq[r] + (n * n) * tqq[r] + taa[r]);
+            }
+            if (ok) {
+                r16::store_block(tsb, nb, q, so);
+                r16::store_block(tab, nb, q, Z4);
+            }
+        }
+    }
+    A16 gg, tgg;
+#pragma unroll
+    for (int ch = 0; ch < NB; ++ch) {
+        const f32x4* wl = pipe.acquire();
+        f32x4 a0 = r16::load_block(vec + UV::B2 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B2 * F, 2 * ch + 1, q);
+        f32x4 b0 = Z4, b1 = Z4;
+        r16::gemm_bt(a0, a1, h2, wl, lane);
+        r16::gemm_bt(b0, b1, th2, wl, lane);
+        gg.b[2 * ch] = a0; gg.b[2 * ch + 1] = a1; tgg.b[2 * ch] = b0; tgg.b[2 * ch + 1] = b1;
+        pipe.release();
+    }
+    // ---- phase C: tv = tv_eff + (U tv_eff) gates + (U v_eff) tgates, one component at a time (U chunks repeated per component)
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        OP ve, tve;
+        {
+            A16 t, u;
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+                const f32x4 vc = r16::load_block(vb + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
+                const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
+                const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
+                t.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);
+                u.b[nb] = r16::load_block(tdb + c * F, nb, q);
+            }
+            ve.set(t); tve.set(u);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4;
+            r16::gemm_bt(a0, a1, ve, wl, lane);
+            r16::gemm_bt(b0, b1, tve, wl, lane);
+            pipe.release();
+            const f32x4 e0 = r16::load_block(tdb + c * F, 2 * ch, q), e1 = r16::load_block(tdb + c * F, 2 * ch + 1, q);
+            if (ok) {
+                r16::store_block(tvb + c * F, 2 * ch, q, e0 + (b0 * gg.b[2 * ch] + a0 * tgg.b[2 * ch]));
+                r16::store_block(tvb + c * F, 2 * ch + 1, q, e1 + (b1 * gg.b[2 * ch + 1] + a1 * tgg.b[2 * ch + 1]));
+                r16::store_block(tdb + c * F, 2 * ch, q, Z4);
+                r16::store_block(tdb + c * F, 2 * ch + 1, q, Z4);
+            }
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) r16::store_block(tcb + c * F, nb, q, Z4);
+    }
+    // ---- phase D: tangent of P for the next message block (no bias)
+    if (p.has_next) {
+        OP sn;
+        {
+            A16 t;
+            r16::load_set(t, tsb, q);
+            sn.set(t);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = Z4, a1 = Z4;
+            r16::gemm_bt(a0, a1, sn, wl, lane);
+            pipe.release();
+            if (ok) { r16::store_block(p.tP + (size_t)nd * F, 2 * ch, q, a0); r16::store_block(p.tP + (size_t)nd * F, 2 * ch + 1, q, a1); }
+        }
+    }
+}
+
+// ================================================================================================== tangent readout kernel
+// tout[vnode][c] = (Vr . tv_c) gate + (Vr . v_c) tgate   (LayerReadout.forward, cpainn.py:425-437)
+template <int NBK, bool SPLIT>
+__global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpReadoutParams p)
+{
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    float* vec = reinterpret_cast<float*>(lds + 4 * CH4);
+    for (int i = threadIdx.x; i < RV::COUNT * F / 4; i += T)
+        reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
+    PipeDMA<NB, T, 2> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+
+    const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
+    const bool ok = node < p.N;
+    const long long nd = ok ? node : p.N - 1;
+    const long long vm = nd / p.A, pm = vm / p.D;
+    const size_t pn = (size_t)(pm * p.A + (nd - vm * p.A));
+
+    A16 t, u;
+    {
+        OP ss, tss;
+        {
+            A16 x, y;
+            r16::load_set(x, p.s + pn * F, q);
+            r16::load_set(y, p.ts + (size_t)nd * F, q);
+            ss.set(x); tss.set(y);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(vec + RV::B0 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B0 * F, 2 * ch + 1, q);
+            f32x4 b0 = Z4, b1 = Z4;
+            r16::gemm_bt(a0, a1, ss, wl, lane);
+            r16::gemm_bt(b0, b1, tss, wl, lane);
+            t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
+            pipe.release();
+        }
+    }
+    r16::ln_silu_dual(t, u, vec + RV::G0 * F, vec + RV::BE0 * F, q);
+    {
+        OP h1, th1;
+        h1.set(t); th1.set(u);
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(vec + RV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B1 * F, 2 * ch + 1, q);
+            f32x4 b0 = Z4, b1 = Z4;
+            r16::gemm_bt(a0, a1, h1, wl, lane);
+            r16::gemm_bt(b0, b1, th1, wl, lane);
+            t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
+            pipe.release();
+        }
+    }
+    r16::ln_silu_dual(t, u, vec + RV::G1 * F, vec + RV::BE1 * F, q);
+    float gate = 0.f, tgate = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const f32x4 w = r16::load_block(vec + RV::W2G * F, nb, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gate = fmaf(t.b[nb][r], w[r], gate); tgate = fmaf(u.b[nb][r], w[r], tgate); }
+    }
+    gate = r16::xquarters(gate) + p.b2_gate;
+    tgate = r16::xquarters(tgate);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.f, tacc = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+            const f32x4 w = r16::load_block(vec + RV::VR * F, nb, q);
+            const f32x4 vv = r16::load_block(p.v + (pn * 3 + c) * F, nb, q), tv = r16::load_block(p.tv + ((size_t)nd * 3 + c) * F, nb, q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc = fmaf(vv[r], w[r], acc); tacc = fmaf(tv[r], w[r], tacc); }
+        }
+        acc = r16::xquarters(acc); tacc = r16::xquarters(tacc);
+        if (ok && q == 0) p.tout[nd * 3 + c] = tacc * gate + acc * tgate;
+    }
+}
+
+// div[b] = sum_d tout[b*D + d][d]  (unit seeds: direction d = 3 atom + component is also the flat index inside [A][3])
+__global__ void painn_div_reduce_kernel(const float* __restrict__ tout, long long B, int D, float* __restrict__ div)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += tout[((size_t)b * D + d) * D + d];
+    div[b] = acc;
+}
+
+// ================================================================================================== launchers
+static size_t jvp_edge_lds(int NB) { return 4 * (size_t)256 * NB * 16 + 4 * 128 * 4 + EV::COUNT * (size_t)32 * NB * 4; }
+static size_t jvp_node_lds(int NB, int count) { return 4 * (size_t)256 * NB * 16 + (size_t)count * 32 * NB * 4; }
+
+template <typename K>
+static hipError_t set_lds(K kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#ifdef TI_DEV_NB4_ONLY
+#define TI_SMALL_NB(...)
+#else
+#define TI_SMALL_NB(...) __VA_ARGS__
+#endif
+#define TI_JVP_DISPATCH(NBv, ...) \
+    switch (NBv) {                                                           \
+        TI_SMALL_NB(case 1: { constexpr int NBK = 2; __VA_ARGS__; } break;)  \
+        TI_SMALL_NB(case 2: { constexpr int NBK = 4; __VA_ARGS__; } break;)  \
+        case 4: { constexpr int NBK = 8; __VA_ARGS__; } break;               \
+        TI_SMALL_NB(case 8: { constexpr int NBK = 16; __VA_ARGS__; } break;) \
+        default: return hipErrorInvalidValue;                                \
+    }
+
+template <int NBK>
+static hipError_t configure_jvp_nbk(int NB)
+{
+    hipError_t e;
+    if ((e = set_lds(painn_jvp_edge_kernel<NBK, false>, jvp_edge_lds(NB))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_edge_kernel<NBK, true>, jvp_edge_lds(NB))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_update_kernel<NBK, false>, jvp_node_lds(NB, UV::COUNT))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_update_kernel<NBK, true>, jvp_node_lds(NB, UV::COUNT))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_readout_kernel<NBK, false>, jvp_node_lds(NB, RV::COUNT))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_readout_kernel<NBK, true>, jvp_node_lds(NB, RV::COUNT))) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+hipError_t configure_painn_jvp_kernels(int NBv)
+{
+    TI_JVP_DISPATCH(NBv, return configure_jvp_nbk<NBK>(NBv));
+    return hipSuccess;
+}
+
+hipError_t launch_jvp_edge(int NBv, bool split, const JvpEdgeParams& p, hipStream_t st)
+{
+    const dim3 g((unsigned)((p.n_groups + 3) / 4));
+    const size_t l = jvp_edge_lds(NBv);
+    TI_JVP_DISPATCH(NBv, {
+        if (split) hipLaunchKernelGGL((painn_jvp_edge_kernel<NBK, true>), g, dim3(256), l, st, p);
+        else hipLaunchKernelGGL((painn_jvp_edge_kernel<NBK, false>), g, dim3(256), l, st, p);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_jvp_update(int NBv, bool split, const JvpUpdateParams& p, hipStream_t st)
+{
+    const dim3 g((unsigned)((p.N + 63) / 64));
+    const size_t l = jvp_node_lds(NBv, UV::COUNT);
+    TI_JVP_DISPATCH(NBv, {
+        if (split) hipLaunchKernelGGL((painn_jvp_update_kernel<NBK, true>), g, dim3(256), l, st, p);
+        else hipLaunchKernelGGL((painn_jvp_update_kernel<NBK, false>), g, dim3(256), l, st, p);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_jvp_readout(int NBv, bool split, const JvpReadoutParams& p, hipStream_t st)
+{
+    const dim3 g((unsigned)((p.N + 63) / 64));
+    const size_t l = jvp_node_lds(NBv, RV::COUNT);
+    TI_JVP_DISPATCH(NBv, {
+        if (split) hipLaunchKernelGGL((painn_jvp_readout_kernel<NBK, true>), g, dim3(256), l, st, p);
+        else hipLaunchKernelGGL((painn_jvp_readout_kernel<NBK, false>), g, dim3(256), l, st, p);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_div_reduce(const float* tout, long long B, int D, float* div, hipStream_t st)
+{
+    hipLaunchKernelGGL(painn_div_reduce_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, tout, B, D, div);
+    return hipGetLastError();
+}
+
+}  // namespace ti

@@ -121,6 +121,10 @@ struct ti_handle {
     std::vector<int> perm;        // sorted row -> original edge index
     DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs, upd_vecs;
     int tap = -1; long long last_B = 0;
+    // forward-mode derivative (painn_jvp_kernels.hip): tangent twins over virtual molecules, sized on first use
+    std::vector<Stream> st_jvp_update; Stream st_jvp_readout{};
+    DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, divb, dl, dlscaled, div2;
+    long long jvp_cap = 0, last_VB = 0; int last_D = 1;
 
     // ---- adw
     ti_adw_desc ad{};
@@ -178,6 +182,7 @@ void build_template(ti_handle* h, const int32_t* src, const int32_t* dst, const 
         if (waste < bestW - 1e-12) { bestW = waste; bestG = G; }
         if (waste <= 0.02) { bestG = G; break; }
     }
+    if (const char* fg = std::getenv("TI_FORCE_G")) bestG = std::max(1, std::min(8, std::atoi(fg)));      // experiments only
     h->G = bestG;
     const int rows = h->G * E;
     h->nblk = (rows + RB - 1) / RB;
@@ -214,15 +219,16 @@ void pack_painn(ti_handle* h, const float* wts)
     if (L > 0) layer(h->phi[0].W0, 2 * F, F, 0);
     else for (int nbo = 0; nbo < NB; ++nbo) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f);
     h->st_embed = end_stream(o);
+    const int NBK = F / 16;
+    const bool split = h->d.precision == TI_PREC_F16X2;
+    auto chunk16 = [&](size_t W, int ld, int n_rows, int row0, int col0) {
+        if (split) pack_chunk16_split(pk, wts + W, ld, n_rows, row0, col0, NBK); else pack_chunk16(pk, wts + W, ld, n_rows, row0, col0, NBK);
+    };
+    auto layer16 = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) chunk16(W, ld, n_rows, 32 * nbo, col0); };
+    auto pad_even = [&](size_t off4) { if (((pk.size() / 4 - off4) / (256 * (size_t)NB)) % 2) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f); };
     for (int l = 0; l < L; ++l) {
         const bool first = l == 0, last = l == L - 1;
         o = begin_stream();                          // edge kernel: 16-row chunk format
-        const int NBK = F / 16;
-        const bool split = h->d.precision == TI_PREC_F16X2;
-        auto chunk16 = [&](size_t W, int ld, int n_rows, int row0, int col0) {
-            if (split) pack_chunk16_split(pk, wts + W, ld, n_rows, row0, col0, NBK); else pack_chunk16(pk, wts + W, ld, n_rows, row0, col0, NBK);
-        };
-        auto layer16 = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) chunk16(W, ld, n_rows, 32 * nbo, col0); };
         layer16(h->w[l].W0, F, F, 0); layer16(h->w[l].W1, F, F, 0);
         layer16(h->phi[l].W0, 2 * F, F, F);        // the e half of [s[src] | e]
         layer16(h->phi[l].W1, F, F, 0);
@@ -245,13 +251,37 @@ void pack_painn(ti_handle* h, const float* wts)
         layer16(h->upd[l].W2, F, 3 * F, 0);                                           // gates
         layer16(h->U[l], F, F, 0);                                                    // phase C
         if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);                            // phase D
-        if (((pk.size() / 4 - o) / (256 * (size_t)NB)) % 2) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f);   // whole superchunks
+        pad_even(o);                                                                  // whole superchunks
         h->st_update.push_back(end_stream(o));
+        o = begin_stream();                          // tangent update kernel: same order, V and U once per spatial component
+        for (int c = 0; c < 3; ++c) layer16(h->V[l], F, F, 0);
+        layer16(h->upd[l].W0, 2 * F, F, 0); layer16(h->upd[l].W0, 2 * F, F, F);
+        layer16(h->upd[l].W1, F, F, 0);
+        for (int nbo = 0; nbo < NB; ++nbo) {
+            chunk16(h->upd[l].W2, F, 3 * F, F + 32 * nbo, 0);
+            chunk16(h->upd[l].W2, F, 3 * F, 2 * F + 32 * nbo, 0);
+        }
+        layer16(h->upd[l].W2, F, 3 * F, 0);
+        for (int c = 0; c < 3; ++c) layer16(h->U[l], F, F, 0);
+        if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);
+        pad_even(o);
+        h->st_jvp_update.push_back(end_stream(o));
     }
     o = begin_stream();
     layer(h->readout.W0, F, F, 0); layer(h->readout.W1, F, F, 0);
     h->st_readout = end_stream(o);
+    o = begin_stream();                              // tangent readout kernel: 16-row chunk format
+    layer16(h->readout.W0, F, F, 0); layer16(h->readout.W1, F, F, 0);
+    pad_even(o);
+    h->st_jvp_readout = end_stream(o);
     h->packed.upload(pk);
+    {
+        std::vector<float> rv;                       // order = struct RV in painn_jvp_kernels.hip
+        const MlpOff& r = h->readout;
+        // Vr follows the 2-float readout bias in the canonical layout (h->Vr itself points at an aligned copy inside `flat`)
+        for (size_t off : {r.b0, r.g0, r.be0, r.b1, r.g1, r.be1, r.W2 + (size_t)F, r.b2 + 2}) rv.insert(rv.end(), wts + off, wts + off + F);
+        h->jvp_ro_vecs.upload(rv);
+    }
     // per-layer vector block of the edge kernel (order = struct EV in painn_kernels.hip)
     std::vector<float> ev;
     for (int l = 0; l < L; ++l) {
@@ -282,15 +312,67 @@ void ensure_painn_ws(ti_handle* h, long long B)
     h->s.alloc(N * F); h->P.alloc(N * F);
     h->v.alloc(N * 3 * F); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F); h->dsacc.alloc(N * F);
     h->e.alloc(std::max<size_t>(groups * h->nblk * ti::EDGE_ROWS_PER_BLOCK * F, 1));
+    h->divb.alloc(B); h->div2.alloc(B); h->dl.alloc(B); h->dlscaled.alloc(B);
     h->cap = B;
 }
 
-// one drift evaluation, everything on h->stream; x_dev / out_dev are device pointers [B*A*3]
-void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* cond_dev, long long B, float* out_dev)
+// ---- forward-mode derivative: tangent workspace over VB virtual molecules (ti_internal.hpp: JvpEdgeParams)
+size_t jvp_bytes_per_vm(const ti_handle* h)
+{
+    const size_t A = h->d.n_atoms, F = h->d.n_features;
+    const size_t erows = ((size_t)h->nblk * ti::EDGE_ROWS_PER_BLOCK + h->G - 1) / h->G;
+    return (A * F * 12 + erows * F + A * 3) * sizeof(float);
+}
+
+void ensure_jvp_ws(ti_handle* h, long long VB)
+{
+    if (VB <= h->jvp_cap) return;
+    const size_t A = h->d.n_atoms, F = h->d.n_features, N = (size_t)VB * A;
+    if (N >= ((size_t)1 << 31)) throw std::invalid_argument("too many tangent nodes in one pass (lower TI_JVP_WS_GB)");
+    const size_t groups = ((size_t)VB + h->G - 1) / h->G;
+    h->ts.alloc(N * F); h->tP.alloc(N * F); h->tdsacc.alloc(N * F);
+    h->tv.alloc(N * 3 * F); h->tdvacc.alloc(N * 3 * F); h->tcacc.alloc(N * 3 * F);
+    h->te.alloc(std::max<size_t>(groups * h->nblk * ti::EDGE_ROWS_PER_BLOCK * F, 1));
+    h->tout.alloc(N * 3);
+    h->jvp_cap = VB;
+}
+
+// molecules per tangent pass with D directions each, from the HBM budget TI_JVP_WS_GB (default 48 GB of tangent state)
+long long jvp_chunk_molecules(const ti_handle* h, int D)
+{
+    double gb = 48.0;
+    if (const char* e = std::getenv("TI_JVP_WS_GB")) gb = std::max(0.001, std::atof(e));
+    const double per_mol = (double)jvp_bytes_per_vm(h) * D;
+    const long long by_mem = (long long)(gb * 1e9 / per_mol);
+    const long long by_index = (long long)(((size_t)1 << 31) - 1) / ((long long)D * h->d.n_atoms);
+    return std::max<long long>(1, std::min(by_mem, by_index));
+}
+
+struct JvpRun {            // one tangent pass riding on a drift evaluation
+    int D;                 // seed directions per molecule
+    const float* xdot;     // D == 1: explicit direction [B*A*3] (device); NULL: unit seeds, D = 3A
+    float* tout;           // [B*D*A*3] tangent of the drift (device)
+};
+
+// one drift evaluation, everything on h->stream; x_dev / out_dev are device pointers [B*A*3].  With `jr` the tangent
+// kernels run in lock step: each reads the primal state its layer's primal kernel is about to overwrite.
+void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* cond_dev, long long B, float* out_dev,
+                     const JvpRun* jr = nullptr)
 {
     const int A = h->d.n_atoms, F = h->d.n_features, L = h->d.n_layers, NB = h->NB;
     const long long N = B * A, groups = (B + h->G - 1) / h->G;
     hipStream_t st = h->stream;
+    const bool split = h->d.precision == TI_PREC_F16X2;
+    const long long VB = jr ? B * jr->D : 0, VN = VB * A, vgroups = (VB + h->G - 1) / h->G;
+    if (jr) {
+        ensure_jvp_ws(h, VB);
+        h->last_VB = VB; h->last_D = jr->D;
+        const size_t nb = (size_t)VN * F * sizeof(float);
+        HIP_CHECK(hipMemsetAsync(h->ts.p, 0, nb, st)); HIP_CHECK(hipMemsetAsync(h->tP.p, 0, nb, st));
+        HIP_CHECK(hipMemsetAsync(h->tdsacc.p, 0, nb, st));
+        HIP_CHECK(hipMemsetAsync(h->tv.p, 0, 3 * nb, st)); HIP_CHECK(hipMemsetAsync(h->tdvacc.p, 0, 3 * nb, st));
+        HIP_CHECK(hipMemsetAsync(h->tcacc.p, 0, 3 * nb, st));
+    }
     const size_t vbytes = (size_t)N * 3 * F * sizeof(float);
     HIP_CHECK(hipMemsetAsync(h->v.p, 0, vbytes, st));
     HIP_CHECK(hipMemsetAsync(h->dvacc.p, 0, vbytes, st));
@@ -309,6 +391,17 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     h->last_B = B;
     if (h->tap == 0) return;
     for (int l = 0; l < L; ++l) {
+        if (jr && h->nblk > 0) {
+            JvpEdgeParams p{};
+            p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
+            p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p;
+            p.nblk = h->nblk; p.G = h->G; p.A = A; p.E = h->d.n_edges; p.D = jr->D; p.first = l == 0; p.last = l == L - 1;
+            p.B = B; p.VB = VB; p.n_groups = vgroups; p.length_scale = h->d.length_scale;
+            p.x = x_dev; p.xdot = jr->xdot; p.P = h->P.p; p.v = h->v.p; p.e = h->e.p; p.tP = h->tP.p; p.tv = h->tv.p;
+            p.te = h->te.p; p.tdsacc = h->tdsacc.p; p.tdvacc = h->tdvacc.p; p.tcacc = h->tcacc.p;
+            Timed tm(h, TI_KERNEL_PAINN_JVP_EDGE);
+            HIP_CHECK(launch_jvp_edge(NB, split, p, st));
+        }
         if (h->nblk > 0) {
             EdgeParams p{};
             p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
@@ -319,6 +412,15 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, h->d.precision == TI_PREC_F16X2, p, st));
         }
         if (h->tap == 1 + 2 * l) return;
+        if (jr) {
+            JvpUpdateParams p{};
+            p.stream = h->S(h->st_jvp_update[l]); p.nch = h->st_jvp_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
+            p.N = VN; p.A = A; p.D = jr->D; p.has_next = l + 1 < L;
+            p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p;
+            p.ts = h->ts.p; p.tv = h->tv.p; p.tdsacc = h->tdsacc.p; p.tdvacc = h->tdvacc.p; p.tcacc = h->tcacc.p; p.tP = h->tP.p;
+            Timed tm(h, TI_KERNEL_PAINN_JVP_UPDATE);
+            HIP_CHECK(launch_jvp_update(NB, split, p, st));
+        }
         {
             UpdateParams p{};
             p.stream = h->S(h->st_update[l]); p.nch = h->st_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
@@ -328,6 +430,13 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         }
         if (h->tap == 2 + 2 * l) return;
     }
+    if (jr) {
+        JvpReadoutParams p{};
+        p.stream = h->S(h->st_jvp_readout); p.nch = h->st_jvp_readout.nch; p.vecs = h->jvp_ro_vecs.p; p.b2_gate = h->b2_gate;
+        p.N = VN; p.A = A; p.D = jr->D; p.s = h->s.p; p.v = h->v.p; p.ts = h->ts.p; p.tv = h->tv.p; p.tout = jr->tout;
+        Timed tm(h, TI_KERNEL_PAINN_JVP_READOUT);
+        HIP_CHECK(launch_jvp_readout(NB, split, p, st));
+    }
     {
         ReadoutParams p{};
         p.stream = h->S(h->st_readout); p.nch = h->st_readout.nch; p.mlp = h->vec(h->readout);
@@ -336,6 +445,22 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         Timed tm(h, TI_KERNEL_PAINN_READOUT);
         HIP_CHECK(launch_readout(NB, p, st));
     }
+}
+
+// drift and exact divergence: 3A unit-seed tangent passes per molecule, in chunks that fit the tangent HBM budget
+void painn_drift_div_dev(ti_handle* h, const float* x_dev, float t, const float* cond_dev, long long B, float* out_dev, float* div_dev)
+{
+    const int A = h->d.n_atoms, D = 3 * A;
+    const long long chunk = jvp_chunk_molecules(h, D);
+    for (long long b0 = 0; b0 < B; b0 += chunk) {
+        const long long bc = std::min(chunk, B - b0);
+        ensure_jvp_ws(h, bc * D);
+        JvpRun jr{D, nullptr, h->tout.p};
+        painn_drift_dev(h, x_dev + (size_t)b0 * A * 3, t, cond_dev ? cond_dev + (size_t)b0 * A * h->ncond : nullptr, bc,
+                        out_dev + (size_t)b0 * A * 3, &jr);
+        HIP_CHECK(launch_div_reduce(h->tout.p, bc, D, div_dev + b0, h->stream));
+    }
+    h->last_B = std::min(chunk, B);
 }
 
 // ------------------------------------------------------------------------------------------------ adw helpers
@@ -391,7 +516,11 @@ void ensure_adw_ws(ti_handle* h, long long B)
 // ------------------------------------------------------------------------------------------------ shared rollout
 // drift(x_dev, t, out_dev) evaluates the drift; state arrays have n floats; comps = floats per trajectory
 // Optional second state of the reference ODE: d(dlogp)/dt = -div * 1e-2, returned * 1e2 (adw/thermo/integrators.py:38-68).
-struct DlogpAux { float *dl = nullptr, *d1 = nullptr, *d2 = nullptr, *scaled = nullptr, *out = nullptr; };
+struct DlogpAux {
+    float *dl = nullptr, *d1 = nullptr, *d2 = nullptr, *scaled = nullptr, *out = nullptr;
+    size_t n_dl = 0;                              // entries of the second state (0: same as the first state's n)
+    float div_scale = 1e-2f, out_scale = 100.0f;  // d(dlogp)/dt = -div_scale * div, written * out_scale
+};
 
 // drift(x_dev, t, out_b, out_div) evaluates the drift (and the divergence if out_div != NULL); state arrays have n floats
 template <typename Drift>
@@ -401,11 +530,12 @@ int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1,
     hipStream_t st = h->stream;
     const hipMemcpyKind out_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     int64_t row = 0, fe = 0;
-    if (aux.dl) HIP_CHECK(hipMemsetAsync(aux.dl, 0, n * sizeof(float), st));
+    const size_t ndl = aux.n_dl ? aux.n_dl : n;
+    if (aux.dl) HIP_CHECK(hipMemsetAsync(aux.dl, 0, ndl * sizeof(float), st));
     auto save = [&]() {
         if (aux.dl) {
-            HIP_CHECK(launch_scale(aux.scaled, aux.dl, 100.0f, (long long)n, st));
-            HIP_CHECK(hipMemcpyAsync(aux.out + (size_t)row * n, aux.scaled, n * sizeof(float), out_kind, st));
+            HIP_CHECK(launch_scale(aux.scaled, aux.dl, aux.out_scale, (long long)ndl, st));
+            HIP_CHECK(hipMemcpyAsync(aux.out + (size_t)row * ndl, aux.scaled, ndl * sizeof(float), out_kind, st));
         }
         HIP_CHECK(hipMemcpyAsync(out_path + (size_t)(row++) * n, x, n * sizeof(float), out_kind, st));
     };
@@ -417,11 +547,11 @@ int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1,
             { Timed tm(h, TI_KERNEL_INTEGRATE); HIP_CHECK(launch_axpy(xt, x, dt, b1, (long long)n, st)); }
             drift(xt, rd->t_grid[k + 1], b2, aux.d2); ++fe;
             { Timed tm(h, TI_KERNEL_INTEGRATE); HIP_CHECK(launch_heun(x, 0.5f * dt, b1, b2, (long long)n, st)); }
-            if (aux.dl) HIP_CHECK(launch_heun(aux.dl, -0.5f * dt * 1e-2f, aux.d1, aux.d2, (long long)n, st));
+            if (aux.dl) HIP_CHECK(launch_heun(aux.dl, -0.5f * dt * aux.div_scale, aux.d1, aux.d2, (long long)ndl, st));
         } else {
             Timed tm(h, TI_KERNEL_INTEGRATE);
             HIP_CHECK(launch_axpy(x, x, dt, b1, (long long)n, st));
-            if (aux.dl) HIP_CHECK(launch_axpy(aux.dl, aux.dl, -dt * 1e-2f, aux.d1, (long long)n, st));
+            if (aux.dl) HIP_CHECK(launch_axpy(aux.dl, aux.dl, -dt * aux.div_scale, aux.d1, (long long)ndl, st));
             if (rd->scheme == TI_SCHEME_EM && rd->eps > 0.0f)
                 HIP_CHECK(launch_noise(x, std::sqrt(2.0f * rd->eps * std::fabs(dt)), rd->seed, rd->traj_offset, k, B, comps,
                                        rd->com_free_noise ? atoms_for_com : 0, st));
@@ -543,6 +673,7 @@ ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t 
         build_template(h.get(), edge_src, edge_dst, edge_type);
         pack_painn(h.get(), weights);
         HIP_CHECK(configure_painn_kernels(h->NB));
+        HIP_CHECK(configure_painn_jvp_kernels(h->NB));
         out = h.release();
         return TI_OK;
     });
@@ -601,6 +732,95 @@ int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, c
     });
 }
 
+int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t, const float* cond, int64_t B, float* out,
+                       float* out_tan, int mem)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (B < 0 || (B > 0 && (!x || !xdot || !out || !out_tan || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
+    if (B == 0) return TI_OK;
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_painn_ws(h, B);
+        ensure_jvp_ws(h, B);
+        const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
+        const float *xd = x, *td = xdot, *cd = cond; float *od = out, *otd = out_tan;
+        if (mem == TI_MEM_HOST) {
+            HIP_CHECK(hipMemcpyAsync(h->x.p, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(h->xt.p, xdot, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            if (nc) HIP_CHECK(hipMemcpyAsync(h->cond.p, cond, nc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            xd = h->x.p; td = h->xt.p; cd = h->cond.p; od = h->b1.p; otd = h->tout.p;
+        }
+        JvpRun jr{1, td, otd};
+        painn_drift_dev(h, xd, t, cd, B, od, &jr);
+        if (mem == TI_MEM_HOST && h->tap < 0) {
+            HIP_CHECK(hipMemcpyAsync(out, od, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipMemcpyAsync(out_tan, otd, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return TI_OK;
+    });
+}
+
+int ti_painn_drift_div(ti_handle* h, const float* x, float t, const float* cond, int64_t B, float* out, float* out_div, int mem)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (B < 0 || (B > 0 && (!x || !out || !out_div || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
+    if (B == 0) return TI_OK;
+    if (h->tap >= 0) return fail(TI_E_ARG, "debug taps apply to ti_painn_drift / ti_painn_drift_jvp only");
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_painn_ws(h, B);
+        const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
+        const float *xd = x, *cd = cond; float *od = out, *dd = out_div;
+        if (mem == TI_MEM_HOST) {
+            HIP_CHECK(hipMemcpyAsync(h->x.p, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            if (nc) HIP_CHECK(hipMemcpyAsync(h->cond.p, cond, nc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            xd = h->x.p; cd = h->cond.p; od = h->b1.p; dd = h->divb.p;
+        }
+        painn_drift_div_dev(h, xd, t, cd, B, od, dd);
+        if (mem == TI_MEM_HOST) {
+            HIP_CHECK(hipMemcpyAsync(out, od, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipMemcpyAsync(out_div, dd, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return TI_OK;
+    });
+}
+
+int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* rd, const float* x0, const float* cond, int64_t B, float div_scale,
+                           float out_scale, int reverse_ode, float* out_path, float* out_dlogp, int64_t* n_fevals)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (int rc = check_rollout_desc(rd)) return rc;
+    if (rd->scheme == TI_SCHEME_EM) return fail(TI_E_UNSUPPORTED, "dlogp is defined for the deterministic schemes only (EULER, HEUN)");
+    if (B < 0 || (B > 0 && (!x0 || !out_path || !out_dlogp || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
+    if (B == 0) { if (n_fevals) *n_fevals = 0; return TI_OK; }
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_painn_ws(h, B);
+        const int A = h->d.n_atoms;
+        const size_t n = (size_t)B * A * 3, nc = (size_t)B * A * h->ncond;
+        const hipMemcpyKind in_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIP_CHECK(hipMemcpyAsync(h->x.p, x0, n * sizeof(float), in_kind, h->stream));
+        const float* cd = cond;
+        if (rd->mem == TI_MEM_HOST && nc) { HIP_CHECK(hipMemcpyAsync(h->cond.p, cond, nc * sizeof(float), hipMemcpyHostToDevice, h->stream)); cd = h->cond.p; }
+        const int saved_tap = h->tap; h->tap = -1;
+        DlogpAux aux;
+        aux.dl = h->dl.p; aux.d1 = h->divb.p; aux.d2 = h->div2.p; aux.scaled = h->dlscaled.p; aux.out = out_dlogp;
+        aux.n_dl = (size_t)B; aux.div_scale = div_scale; aux.out_scale = out_scale;
+        const int rc = rollout_common(h, rd, h->x.p, h->b1.p, h->b2.p, h->xt.p, n, B, A * 3, A, out_path, n_fevals,
+                                      [&](const float* xs, float t, float* o, float* dv) {
+                                          painn_drift_div_dev(h, xs, t, cd, B, o, dv);
+                                          if (reverse_ode) {      // (-b, +div): ode_wrapper.py:49
+                                              HIP_CHECK(launch_scale(o, o, -1.0f, (long long)n, h->stream));
+                                              HIP_CHECK(launch_scale(dv, dv, -1.0f, (long long)B, h->stream));
+                                          }
+                                      }, aux);
+        h->tap = saved_tap;
+        return rc;
+    });
+}
+
 int ti_painn_debug_tap(ti_handle* h, int stage)
 {
     if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
@@ -645,6 +865,36 @@ int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)
                     const size_t gi = m / h->G, r = (m % h->G) * E + k;          // k = sorted position
                     std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + (gi * h->nblk * RB + r) * F, F * sizeof(float));
                 }
+        } else if (what >= 3 && what <= 5) {
+            // tangents of the last ti_painn_drift_jvp call (one direction per molecule), composed like their primal twins
+            if (h->last_D != 1 || (size_t)h->last_VB != B) return fail(TI_E_ARG, "tangent taps need a preceding ti_painn_drift_jvp call");
+            auto fetch = [&](const DevBuf<float>& b, size_t n) { std::vector<float> v(n); HIP_CHECK(hipMemcpy(v.data(), b.p, n * sizeof(float), hipMemcpyDeviceToHost)); return v; };
+            if (what == 3) {
+                if (n_floats != N * F) return fail(TI_E_ARG, "size mismatch (ts)");
+                const auto ts = fetch(h->ts, n_floats), td = fetch(h->tdsacc, n_floats);
+                for (size_t i = 0; i < n_floats; ++i) out[i] = ts[i] + td[i];
+            } else if (what == 4) {
+                if (n_floats != N * 3 * F) return fail(TI_E_ARG, "size mismatch (tv)");
+                const auto v = fetch(h->v, n_floats), cc = fetch(h->cacc, n_floats);
+                const auto tv = fetch(h->tv, n_floats), tdv = fetch(h->tdvacc, n_floats), tcc = fetch(h->tcacc, n_floats);
+                for (size_t nd = 0; nd < N; ++nd)
+                    for (size_t f = 0; f < F; ++f)
+                        for (int c = 0; c < 3; ++c) {
+                            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                            auto at = [&](const std::vector<float>& a, int cc2) { return a[(nd * 3 + cc2) * F + f]; };
+                            out[(nd * 3 + c) * F + f] = (at(tv, c) + at(tdv, c)) + ((at(tcc, c1) * at(v, c2) + at(cc, c1) * at(tv, c2)) -
+                                                                                     (at(tcc, c2) * at(v, c1) + at(cc, c2) * at(tv, c1)));
+                        }
+            } else {
+                if (n_floats != B * E * F) return fail(TI_E_ARG, "size mismatch (te)");
+                const size_t RB = ti::EDGE_ROWS_PER_BLOCK, groups = (B + h->G - 1) / h->G, rows = groups * h->nblk * RB;
+                const auto e = fetch(h->te, rows * F);
+                for (size_t m = 0; m < B; ++m)
+                    for (size_t k = 0; k < E; ++k) {
+                        const size_t gi = m / h->G, r = (m % h->G) * E + k;
+                        std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + (gi * h->nblk * RB + r) * F, F * sizeof(float));
+                    }
+            }
         } else return fail(TI_E_ARG, "unknown tap");
         return TI_OK;
     });

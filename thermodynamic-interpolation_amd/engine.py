@@ -147,14 +147,56 @@ class PainnEngine(_Engine):
         _lib.check(_lib.lib().ti_painn_rollout(self.h, C.byref(rd), xp, cp, B, op, C.byref(nfe)))
         return out, nfe.value
 
+    # ---- forward-mode derivative, exact divergence, dlogp
+    def jvp(self, x, xdot, t, cond=None):
+        """(b(x), (d b / d x) xdot), both [B,A,3]."""
+        B = int(x.shape[0])
+        if tuple(x.shape[1:]) != (self.A, 3) or tuple(xdot.shape) != tuple(x.shape):
+            raise ValueError(f"x and xdot must be [B,{self.A},3]")
+        xp, cp, dev, keep = self._bufs(x, cond)
+        tp, tk, tdev = _lib.as_ptr(xdot)
+        if tdev != dev:
+            raise ValueError("xdot must live where x lives")
+        out, tan = _alloc_like(x if dev else None, (B, self.A, 3)), _alloc_like(x if dev else None, (B, self.A, 3))
+        _lib.check(_lib.lib().ti_painn_drift_jvp(self.h, xp, tp, float(t), cp, B, _lib.as_ptr(out)[0], _lib.as_ptr(tan)[0],
+                                                 _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+        return out, tan
+
+    def drift_div(self, x, t, cond=None):
+        """(b(x) [B,A,3], div [B]) with div = sum_ij d b_ij / d x_ij -- the reference's compute_divergence without its 1e-2."""
+        B = int(x.shape[0])
+        if tuple(x.shape[1:]) != (self.A, 3):
+            raise ValueError(f"x must be [B,{self.A},3]")
+        xp, cp, dev, keep = self._bufs(x, cond)
+        out, div = _alloc_like(x if dev else None, (B, self.A, 3)), _alloc_like(x if dev else None, (B,))
+        _lib.check(_lib.lib().ti_painn_drift_div(self.h, xp, float(t), cp, B, _lib.as_ptr(out)[0], _lib.as_ptr(div)[0],
+                                                 _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+        return out, div
+
+    def rollout_dlogp(self, x0, cond, t_grid, scheme="euler", save_every=1, div_scale=1.0, out_scale=1.0, reverse_ode=False):
+        """Two-state rollout (x, dlogp): returns (path [rows,B,A,3], dlogp [rows,B], n_fevals).  d(dlogp)/dt = -div_scale * div
+        (reverse_ode: (-b, +div_scale * div) on the descending grid the caller passes), dlogp is written * out_scale."""
+        B = int(x0.shape[0])
+        if tuple(x0.shape[1:]) != (self.A, 3):
+            raise ValueError(f"x0 must be [B,{self.A},3]")
+        xp, cp, dev, keep = self._bufs(x0, cond)
+        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, 0.0, 0, 0, False)
+        rows = int(_lib.lib().ti_rollout_rows(rd.n_step, rd.save_every))
+        out, dl = _alloc_like(x0 if dev else None, (rows, B, self.A, 3)), _alloc_like(x0 if dev else None, (rows, B))
+        nfe = C.c_int64(0)
+        _lib.check(_lib.lib().ti_painn_rollout_dlogp(self.h, C.byref(rd), xp, cp, B, float(div_scale), float(out_scale), int(bool(reverse_ode)),
+                                                     _lib.as_ptr(out)[0], _lib.as_ptr(dl)[0], C.byref(nfe)))
+        return out, dl, nfe.value
+
     # ---- parity-test taps
     def debug_tap(self, stage: int):
         _lib.check(_lib.lib().ti_painn_debug_tap(self.h, int(stage)))
 
     def debug_read(self, what: str, B: int):
-        shape = {"s": (B, self.A, self.F), "v": (B, self.A, 3, self.F), "e": (B, self.E, self.F)}[what]
+        """what: 's' | 'v' | 'e', or 'ts' | 'tv' | 'te' for the tangents of the last jvp() call."""
+        shape = {"s": (B, self.A, self.F), "v": (B, self.A, 3, self.F), "e": (B, self.E, self.F)}[what[-1]]
         out = np.empty(shape, np.float32)
-        _lib.check(_lib.lib().ti_painn_debug_read(self.h, {"s": 0, "v": 1, "e": 2}[what], _lib.fptr(out), out.size))
+        _lib.check(_lib.lib().ti_painn_debug_read(self.h, {"s": 0, "v": 1, "e": 2, "ts": 3, "tv": 4, "te": 5}[what], _lib.fptr(out), out.size))
         return out
 
 
