@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="adw,latent,a9,a25,f256")
+    ap.add_argument("--which", default="adw,latent,a9,a25,f256,div")
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
     import torch
@@ -66,6 +66,41 @@ def main():
         print(json.dumps({"workload": tag, "precision": precision, "trajectory_steps_per_s": B / dt, "ms_per_step": dt * 1e3,
                           "algorithmic_tflops": flop * B / dt / 1e12}))
         eng.close()
+
+    if "div" in which:
+        # exact divergence: drift + trace of the Jacobian, 3A = 54 forward-mode directions per molecule.
+        # Algorithmic work per molecule ~ (1 + 2 * 54 * (L-1)/L ... ) is quoted as the measured ratio to a plain drift instead.
+        F, L, A, B = 128, 5, 18, int(os.environ.get("TI_BENCH_DIV_B", "2048"))
+        src, dst, et = syn.fully_connected_template(A)
+        flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, 0), W.painn_param_spec(0, F, L, 25))
+        x0 = torch.from_numpy(syn.molecule_coords(B, A, 0)).to(dev)
+        cond = torch.from_numpy(syn.ambient_cond(B, A)).to(dev)
+        for prec in ("f16x2", "f32"):
+            eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision=prec)
+            dt_div = timed(lambda k: [eng.drift_div(x0, 0.5, cond) for _ in range(k)])
+            dt_b = timed(lambda k: [eng.drift(x0, 0.5, cond) for _ in range(k)])
+            eng.profile(True)
+            eng.drift_div(x0, 0.5, cond)
+            prof = {k: eng.profile_read(k) for k in ("painn_jvp_edge", "painn_jvp_update", "painn_jvp_readout", "painn_edge", "painn_update")}
+            eng.profile(False)
+            rec = {"workload": f"ambient drift + exact divergence: {B} molecules x 18 atoms, F=128 L=5 (54 tangent directions each)",
+                   "precision": prec, "molecule_div_evals_per_s": B / dt_div, "ms_per_eval": dt_div * 1e3,
+                   "cost_ratio_vs_plain_drift": dt_div / dt_b,
+                   "kernel_ms": {k: round(v[1], 3) for k, v in prof.items()}, "kernel_launches": {k: v[0] for k, v in prof.items()}}
+            if prec == "f32" and not os.environ.get("TI_BENCH_NO_CPU"):
+                from oracle import oracle                       # CPU baseline leg only (oracle/ti_oracle.c header)
+                n_cpu = 8
+                orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+                xc, cc = syn.molecule_coords(n_cpu, A, 0), syn.ambient_cond(n_cpu, A)
+                t0 = time.perf_counter()
+                _, od = orc.drift_div(xc, 0.5, cc, precision=32)
+                t_cpu = time.perf_counter() - t0
+                _, gd = eng.drift_div(xc, 0.5, cc)
+                rec["cpu_oracle_molecule_div_evals_per_s"] = n_cpu / t_cpu
+                rec["cpu_threads"] = oracle.num_threads()
+                rec["max_abs_div_diff_vs_oracle"] = float(np.abs(gd - od).max())
+            print(json.dumps(rec))
+            eng.close()
 
     for prec in ("f16x2", "f32"):
         if "latent" in which:

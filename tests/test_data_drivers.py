@@ -109,6 +109,13 @@ def test_drivers_end_to_end(tmp_path):
     path, _ = eng.rollout(x0, ti.synthetic.ambient_cond(3, A, 1000.0, (300.0,)), ti.engine.time_grid(0, 1, 6), scheme="euler")
     assert rel_l2(samples[:3], path.transpose(1, 0, 2, 3)) < 1e-6        # batches re-centre the (already centred) frames: 1-ulp inputs
 
+    # return_dlogp=1: dlogps_{name}.npy holds the last row of the second state per trajectory (sample_ambient.py:96-100)
+    cfg_d = types.SimpleNamespace(seed=0, batch_size=4, n_steps=3, atol=1e-5, rtol=1e-5, return_dlogp=1, method="euler",
+                                  data_save_path=str(tmp_path / "outd"), data_save_name="d")
+    samples_d, _ = ti.drivers.sample_ambient(cfg_d, b, ds)
+    dl = np.load(tmp_path / "outd" / "dlogps_d.npy")
+    assert samples_d.shape == (7, 3, A, 3) and dl.shape == (7,) and np.isfinite(dl).all() and np.abs(dl).max() > 0
+
     bl = ti.thermo.latent.cPaiNN(n_features=F, score_layers=L, temp_length=75)
     bl.precision = "f16x2"
     lds = d.LatentSamplerDataset(ds.data[0], T=800, n_samples=6, seed=2)

@@ -115,3 +115,33 @@ def test_divergence_full_size_chunked_and_ragged(monkeypatch):
     idx = [0, 7, 8, B - 1]
     _, odiv = orc.drift_div(x[idx], 0.5, cond[idx], precision=64)
     assert (np.abs(div[idx] - odiv) < DIV_ATOL * (np.abs(odiv) + 1.0)).all(), (div[idx], odiv)
+
+
+@pytest.mark.parametrize("name", ["div_ambient_small", "div_latent_multi"])
+def test_molecule_integrator_return_dlogp(name):
+    """The reference-facing API: MoleculeIntegrator(return_dlogp=True).rollout(batch) on a torch batch."""
+    torch = pytest.importorskip("torch")
+    from test_gpu_api import golden_batch, state_dict_of
+    ti = pkg()
+    g = load_golden(name)
+    ambient = int(g["variant"]) == 0
+    mod = ti.thermo.ambient if ambient else ti.thermo.latent
+    kw = dict(n_features=int(g["F"]), score_layers=int(g["L"]), temp_length=int(g["temp_length"]))
+    if not ambient:
+        kw["temperatures"] = [int(x) for x in g["temperatures"]]
+    b = mod.cPaiNN(**kw)
+    b.load_state_dict(state_dict_of(g))
+    batch = golden_batch(g, "atoms" if ambient else "atom_number")
+    n_step = len(g["grid"])
+    for rev in ([False, True] if "grid_rev" in g else [False]):
+        integ = mod.MoleculeIntegrator(b=b, method="heun", n_step=n_step, atol=1e-5, rtol=1e-5, return_dlogp=True, reverse_ode=rev,
+                                       start=0.0, end=1.0)
+        res = integ.rollout(batch)
+        xts, dlogp = res[0], res[1]
+        tag = "heun_rev" if rev else "heun"
+        ref = g[f"traj_{tag}"].reshape(n_step, -1, 3)
+        out_scale = 1e2 if ambient else 1.0                             # ambient/integrators.py:68
+        assert isinstance(dlogp, torch.Tensor) and tuple(dlogp.shape) == (n_step, int(g["B"]))
+        assert rel_l2(xts.numpy() - ref[0], ref - ref[0]) < 2e-5
+        ref_dl = g[f"dlogp_{tag}"] * out_scale
+        assert np.allclose(dlogp.numpy(), ref_dl, rtol=0, atol=DIV_ATOL * (np.abs(ref_dl).max() + 1.0))

@@ -106,8 +106,9 @@ def test_api_mirror_signatures_and_solver_names():
         assert integ.n_step == 100
         with pytest.raises(NotImplementedError, match="torchdiffeq"):
             cls(b=b, method="dopri5", n_step=10)
-        with pytest.raises(NotImplementedError, match="divergence"):
-            cls(b=b, method="euler", n_step=10, return_dlogp=True)
+        assert cls(b=b, method="euler", n_step=10, return_dlogp=True, reverse_ode=True).return_dlogp       # exact divergence: built
+        with pytest.raises(ValueError, match="deterministic"):
+            cls(b=b, method="em", n_step=10, return_dlogp=True, eps=0.1)
         with pytest.raises(ValueError):
             cls(b=b, method="rk45")
     net = adw.FCNetMultiBeta(1, 1, 64, 3)

@@ -1,7 +1,7 @@
 """Sampling drivers with the reference's loop structure and output files.
 
   sample_ambient <- /root/reference/mdqm9/sample_ambient.py:18-119   samples_/dlogps_/latent_noises_/latent_dlogps_{name}.npy
-  sample_latent  <- /root/reference/mdqm9/sample_latent.py:19-96     samples_/dlogps_{name}_forward.npy
+  sample_latent  <- /root/reference/mdqm9/sample_latent.py:19-96     samples_/dlogps_{name}_forward.npy (dlogps with return_dlogp)
   sample_adw     <- /root/reference/adw/sample.py:14-81              initial_samples/samples/dlogps _epoch_{k}.npy under beta_{b0}_to_{b1}/
   load_config    <- /root/reference/mdqm9/thermo/utils.py:31-47      JSON file -> argparse.Namespace (keys become --options)
 
@@ -66,13 +66,17 @@ def sample_latent(config, b, dataset):
     integrator = _lat.MoleculeIntegrator(b=b, method=getattr(config, "method", "heun"), rtol=config.rtol, atol=config.atol,
                                          n_step=config.n_steps, return_dlogp=bool(config.return_dlogp), reverse_ode=False,
                                          save_every=getattr(config, "save_every", 1))
-    samples = []
+    samples, dlogps = [], []
     b.eval()
     for batch in dataset.batches(config.batch_size, seed=config.seed, drop_last=True):
-        sample, _dlogp, bidx = integrator.rollout(batch)
+        sample, dlogp, bidx = integrator.rollout(batch)
         samples.append(_regroup(sample, bidx))
+        if config.return_dlogp:
+            dlogps.append(C.to_numpy(dlogp)[-1, :])                     # sample_latent.py:76-77
     out = np.concatenate(samples, axis=0)
     np.save(os.path.join(config.data_save_path, f"samples_{config.data_save_name}_forward.npy"), out)
+    if config.return_dlogp:
+        np.save(os.path.join(config.data_save_path, f"dlogps_{config.data_save_name}_forward.npy"), np.concatenate(dlogps, axis=0))
     return out
 
 

@@ -39,8 +39,3 @@ def like(result: np.ndarray, template):
         return torch.from_numpy(np.ascontiguousarray(result)).to(template.device)
     return result
 
-
-def dlogp_unsupported():
-    raise NotImplementedError(
-        "return_dlogp=True needs the exact divergence of the drift (autograd trace in the reference, "
-        "models/ode_wrapper.py compute_divergence); it is the next scope row (SURVEY.md §8f-1) and is not built yet.")

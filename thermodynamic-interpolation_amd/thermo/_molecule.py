@@ -123,15 +123,20 @@ class PaiNNShell:
 
 
 class MoleculeIntegratorBase:
-    """rollout(batch) with the reference's constructor; fixed-step schemes only (see _common.check_method)."""
-    SCALE_DLOGP = 1.0
+    """rollout(batch) with the reference's constructor; fixed-step schemes only (see _common.check_method).
+
+    return_dlogp=True integrates the second state of the reference ODEWrapper with the same scheme: d(dlogp)/dt = -DIV_SCALE *
+    div b (exact divergence, 3A forward-mode passes per molecule on the GPU), returned * SCALE_DLOGP as [n_saved, B].  With
+    reverse_ode the pair is (-b, +DIV_SCALE * div) on linspace(end, start) (ode_wrapper.py:49, integrators.py:40-43)."""
+    SCALE_DLOGP = 1.0      # integrators.py:68 (ambient: 1e2)
+    DIV_SCALE = 1.0        # ode_wrapper.py:91 (ambient: 1e-2)
 
     def __init__(self, b, method: str = "dopri5", n_step: int = 100, atol: float = 1e-4, rtol: float = 1e-4, start: float = 0.0,
                  end: float = 1.0, return_dlogp: bool = False, reverse_ode: bool = False, *, eps: float = 0.0, seed: int = 0,
                  save_every: int = 1, com_free_noise: bool = False):
         self.method = C.check_method(method)
-        if return_dlogp:
-            C.dlogp_unsupported()
+        if return_dlogp and self.method == "em" and eps > 0:
+            raise ValueError("return_dlogp=True needs a deterministic scheme ('euler' or 'heun')")
         self.b = b
         self.start, self.end, self.rtol, self.atol = start, end, rtol, atol
         self.n_step, self.return_dlogp, self.reverse_ode = n_step, return_dlogp, reverse_ode
@@ -143,6 +148,13 @@ class MoleculeIntegratorBase:
         # without dlogp the reference always integrates on linspace(start, end) (integrators.py:54-55), reverse_ode or not
         grid = _engine.time_grid(self.start, self.end, self.n_step)
         eng = self.b.engine_for(A, src, dst, ety, ids)
+        if self.return_dlogp:
+            if self.reverse_ode:
+                grid = _engine.time_grid(self.end, self.start, self.n_step)
+            path, dl, nfe = eng.rollout_dlogp(x0, self.b.cond_of(batch, B, A), grid, scheme="euler" if self.method == "em" else self.method,
+                                              save_every=self.save_every, div_scale=self.DIV_SCALE, out_scale=self.SCALE_DLOGP,
+                                              reverse_ode=self.reverse_ode)
+            return C.like(path.reshape(path.shape[0], B * A, 3), batch.x0), C.like(dl, batch.x0), nfe
         path, nfe = eng.rollout(x0, self.b.cond_of(batch, B, A), grid, scheme=self.method, save_every=self.save_every, eps=self.eps,
                                 seed=self.seed, traj_offset=traj_offset, com_free_noise=self.com_free_noise)
         xts = C.like(path.reshape(path.shape[0], B * A, 3), batch.x0)

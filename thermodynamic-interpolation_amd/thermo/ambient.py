@@ -21,6 +21,7 @@ class cPaiNN(PaiNNShell):
 class MoleculeIntegrator(MoleculeIntegratorBase):
     """rollout(batch) -> (xts [n_saved, N, 3], dlogp * 1e2, n_fevals, batch.batch)   (integrators.py:68)"""
     SCALE_DLOGP = 1e2
+    DIV_SCALE = 1e-2
 
     def rollout(self, batch, traj_offset: int = 0):
         xts, dlogp, nfe = self._rollout(batch, traj_offset)
