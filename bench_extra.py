@@ -81,7 +81,7 @@ def main():
             dt_b = timed(lambda k: [eng.drift(x0, 0.5, cond) for _ in range(k)])
             eng.profile(True)
             eng.drift_div(x0, 0.5, cond)
-            prof = {k: eng.profile_read(k) for k in ("painn_jvp_edge", "painn_jvp_update", "painn_jvp_readout", "painn_edge", "painn_update")}
+            prof = {k: eng.profile_read(k) for k in ("painn_jvp_filter", "painn_jvp_edge", "painn_jvp_update", "painn_jvp_readout", "painn_edge", "painn_update")}
             eng.profile(False)
             rec = {"workload": f"ambient drift + exact divergence: {B} molecules x 18 atoms, F=128 L=5 (54 tangent directions each)",
                    "precision": prec, "molecule_div_evals_per_s": B / dt_div, "ms_per_eval": dt_div * 1e3,

@@ -159,7 +159,7 @@ int ti_reserve(ti_handle* h, int64_t B);
 /* Live kernel timing with HIP events on the handle's stream (bench.py roofline leg). */
 enum { TI_KERNEL_PAINN_EDGE = 0, TI_KERNEL_PAINN_UPDATE = 1, TI_KERNEL_PAINN_EMBED = 2, TI_KERNEL_PAINN_READOUT = 3,
        TI_KERNEL_ADW = 4, TI_KERNEL_INTEGRATE = 5, TI_KERNEL_PAINN_JVP_EDGE = 6, TI_KERNEL_PAINN_JVP_UPDATE = 7,
-       TI_KERNEL_PAINN_JVP_READOUT = 8, TI_KERNEL_COUNT = 9 };
+       TI_KERNEL_PAINN_JVP_READOUT = 8, TI_KERNEL_PAINN_JVP_FILTER = 9, TI_KERNEL_COUNT = 10 };
 int ti_profile_enable(ti_handle* h, int on);
 int ti_profile_read(ti_handle* h, int kernel, int64_t* n_launches, double* total_ms);   /* also resets that slot */
 /* Debug taps for parity tests: copy an intermediate of the LAST ti_painn_drift / ti_painn_drift_jvp call to host.

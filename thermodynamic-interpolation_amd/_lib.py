@@ -18,7 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SCHEMES = {"euler": 0, "heun": 1, "em": 2}
 PRECISIONS = {"f32": 0, "f16x2": 1}
 KERNELS = {"painn_edge": 0, "painn_update": 1, "painn_embed": 2, "painn_readout": 3, "adw": 4, "integrate": 5,
-           "painn_jvp_edge": 6, "painn_jvp_update": 7, "painn_jvp_readout": 8}
+           "painn_jvp_edge": 6, "painn_jvp_update": 7, "painn_jvp_readout": 8, "painn_jvp_filter": 9}
 
 # every symbol include/ti_hip.h declares (tests/test_abi.py checks the library exports exactly these)
 ABI_SYMBOLS = [

@@ -563,6 +563,78 @@ __device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd<NBK
 template <int NBK>
 __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK, false>& in, const f32x4* wl, int lane) { gemm_fl(acc0, acc1, in.a, wl, lane); }
 
+// ---- (value, tangent) operand pairs against one weight chunk: every LDS fragment is read once for both products
+template <int NBK, bool FLIP>
+__device__ __forceinline__ void gemm_pair_f32(f32x4& a0, f32x4& a1, f32x4& t0, f32x4& t1, const Act<NBK>& in, const Act<NBK>& tin,
+                                              const f32x4* wl, int lane)
+{
+    f32x4 w0 = wl[lane], w1 = wl[NBK * 64 + lane];
+#pragma unroll
+    for (int nbi = 0; nbi < NBK; ++nbi) {
+        const int nxt = nbi + 1 < NBK ? nbi + 1 : 0;
+        const f32x4 n0 = wl[nxt * 64 + lane], n1 = wl[(NBK + nxt) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (FLIP) {
+                a0 = mfma16(in.b[nbi][r], w0[r], a0); a1 = mfma16(in.b[nbi][r], w1[r], a1);
+                t0 = mfma16(tin.b[nbi][r], w0[r], t0); t1 = mfma16(tin.b[nbi][r], w1[r], t1);
+            } else {
+                a0 = mfma16(w0[r], in.b[nbi][r], a0); a1 = mfma16(w1[r], in.b[nbi][r], a1);
+                t0 = mfma16(w0[r], tin.b[nbi][r], t0); t1 = mfma16(w1[r], tin.b[nbi][r], t1);
+            }
+        }
+        w0 = n0; w1 = n1;
+    }
+}
+template <int NBK, bool FLIP>
+__device__ __forceinline__ void gemm_pair_split_block(f32x4& acc, f32x4& tacc, const Opnd<NBK, true>& in, const Opnd<NBK, true>& tin,
+                                                      const h8* wl, int lane)
+{
+    constexpr int KS = NBK / 2;
+    f32x4 x = {0, 0, 0, 0}, tx = {0, 0, 0, 0};
+    h8 wh = wl[lane], wlo = wl[64 + lane];
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+        const int nx = m + 1 < KS ? m + 1 : m;
+        const h8 nh = wl[(nx * 2 + 0) * 64 + lane], nl = wl[(nx * 2 + 1) * 64 + lane];
+        asm volatile("" ::: "memory");
+        if (FLIP) {
+            acc = mfma16h(in.hi[m], wh, acc); tacc = mfma16h(tin.hi[m], wh, tacc);
+            x = mfma16h(in.lo[m], wh, x); tx = mfma16h(tin.lo[m], wh, tx);
+            x = mfma16h(in.hi[m], wlo, x); tx = mfma16h(tin.hi[m], wlo, tx);
+        } else {
+            acc = mfma16h(wh, in.hi[m], acc); tacc = mfma16h(wh, tin.hi[m], tacc);
+            x = mfma16h(wh, in.lo[m], x); tx = mfma16h(wh, tin.lo[m], tx);
+            x = mfma16h(wlo, in.hi[m], x); tx = mfma16h(wlo, tin.hi[m], tx);
+        }
+        wh = nh; wlo = nl;
+    }
+    acc += x * 4.8828125e-4f;
+    tacc += tx * 4.8828125e-4f;
+}
+template <int NBK>
+__device__ __forceinline__ void gemm_bt2(f32x4& a0, f32x4& a1, f32x4& t0, f32x4& t1, const Opnd<NBK, false>& in, const Opnd<NBK, false>& tin,
+                                         const f32x4* wl, int lane) { gemm_pair_f32<NBK, false>(a0, a1, t0, t1, in.a, tin.a, wl, lane); }
+template <int NBK>
+__device__ __forceinline__ void gemm_fl2(f32x4& a0, f32x4& a1, f32x4& t0, f32x4& t1, const Opnd<NBK, false>& in, const Opnd<NBK, false>& tin,
+                                         const f32x4* wl, int lane) { gemm_pair_f32<NBK, true>(a0, a1, t0, t1, in.a, tin.a, wl, lane); }
+template <int NBK>
+__device__ __forceinline__ void gemm_bt2(f32x4& a0, f32x4& a1, f32x4& t0, f32x4& t1, const Opnd<NBK, true>& in, const Opnd<NBK, true>& tin,
+                                         const f32x4* wl4, int lane)
+{
+    const h8* wl = reinterpret_cast<const h8*>(wl4);
+    gemm_pair_split_block<NBK, false>(a0, t0, in, tin, wl, lane);
+    gemm_pair_split_block<NBK, false>(a1, t1, in, tin, wl + NBK * 64, lane);
+}
+template <int NBK>
+__device__ __forceinline__ void gemm_fl2(f32x4& a0, f32x4& a1, f32x4& t0, f32x4& t1, const Opnd<NBK, true>& in, const Opnd<NBK, true>& tin,
+                                         const f32x4* wl4, int lane)
+{
+    const h8* wl = reinterpret_cast<const h8*>(wl4);
+    gemm_pair_split_block<NBK, true>(a0, t0, in, tin, wl, lane);
+    gemm_pair_split_block<NBK, true>(a1, t1, in, tin, wl + NBK * 64, lane);
+}
+
 }  // namespace r16
 
 }  // namespace ti

@@ -2,13 +2,23 @@
 // reference obtains with 3A reverse-mode passes (ODEWrapper.compute_divergence,
 // /root/reference/mdqm9/thermo/ambient/models/ode_wrapper.py:59-91; latent twin ode_wrapper.py:57-86).
 //
-// A "virtual molecule" vm = b * D + d is molecule b differentiated along seed direction d.  D = 3A with unit seeds
+// Virtual molecules.  Molecule b differentiated along seed direction d is a "virtual molecule".  D = 3A with unit seeds
 // (d perturbs atom d / 3, component d % 3) gives the Jacobian diagonal, D = 1 with an explicit xdot an arbitrary JVP.
-// The kernels here carry ONLY tangents in HBM (ts, tv, te, tP and the three accumulators, laid out like their primal
-// twins but over virtual molecules).  Primal state is read from the ordinary drift pipeline, which the host runs in
-// lock step (ti_api.hip: tangent edge -> primal edge -> tangent update -> primal update per layer), and the primal
-// activations a tangent needs (LayerNorm statistics, SiLU slopes, gate values) are recomputed in registers next to it:
-// every matrix product below runs on (activation, tangent) pairs against the same weight chunk in LDS.
+// They are grouped like the primal molecules: primal group pg (G molecules, one wave) and direction d form virtual group
+// vg = pg * D + d, whose G members are the G molecules of pg -- so virtual row (blk, j) IS primal row (blk, j) of group pg
+// (same edge, same slot), and the D directions of one primal group are neighbours in the launch (their primal reads hit L2).
+//   virtual molecule vm = vg * G + m  <->  molecule pm = pg * G + m;   virtual node = vm * A + atom.
+// The kernels carry ONLY tangents in HBM (ts, tv, te, tP and three accumulators, laid out like their primal twins over
+// virtual molecules).  Primal state is read from the ordinary drift pipeline, which the host runs in lock step
+// (ti_api.hip: [filter pass ->] tangent edge -> primal edge -> tangent update -> primal update per layer); the primal
+// activations a tangent needs (LayerNorm statistics, SiLU slopes, gate values) are recomputed in registers next to it, every
+// matrix product runs on a (value, tangent) operand pair against one weight chunk in LDS.
+//
+// The filter branch w(enc(|r|)) depends on x only through the edge length, so its tangent is rank one:
+//   d w_o[edge][dir] = d|r|[edge][dir] * Q[edge],  Q = (d w_o / d |r|).
+// painn_jvp_filter_kernel evaluates w_o and Q ONCE per primal edge and layer (a dual pass seeded with d|r| = 1) and parks
+// them in HBM in the register layout of the flipped output stage; the per-direction edge kernel then runs only the phi
+// branch -- half the matrix work of differentiating both branches per direction.
 //
 // Tangent rules restated from the forward pass (painn_kernels.hip; reference lines there):
 //   geometry  r = x_s - x_d, d = |r|, dir = r / (1 + d):   dd = r.dr / d,  ddir = dr / (1 + d) - r dd / (1 + d)^2
@@ -40,17 +50,19 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 
 }  // namespace
 
-// ================================================================================================== tangent edge kernel
+// ================================================================================================== filter pass
+// w_o + bias and Q = d w_o / d |r| of every primal edge of this layer, in the flipped-accumulator layout:
+//   wq[((((pg * nblk + blk) * 5 + c) * NB + nbo) * 4 + k) * 64 + lane]   k: 0/1 = w_o features 32 nbo + {0,16} + (lane & 15),
+//   2/3 = Q of the same; float4 = the block's rows 4 (lane >> 4) .. + 3.   One wave per primal group.
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgeParams p)
+__global__ __launch_bounds__(256, 1) void painn_jvp_filter_kernel(const JvpFilterParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
     using OP = r16::Opnd<NBK, SPLIT>;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    float* scratch = reinterpret_cast<float*>(lds + 4 * CH4) + wave * 128;         // [16 rows][8]: edge_dir, 0, its tangent, 0
-    float* vec = reinterpret_cast<float*>(lds + 4 * CH4) + WAVES * 128;            // [EV::COUNT][F]
+    float* vec = reinterpret_cast<float*>(lds + 4 * CH4);                           // [EV::COUNT][F]
     for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
     PipeDMA<NB, T, 2> pipe;
@@ -62,17 +74,106 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
     const bool first = p.first != 0, last = p.last != 0;
 
     for (int blk = 0; blk < p.nblk; ++blk) {
+        const uint32_t meta = p.rows[blk * 16 + j];
+        long long pm = gi * p.G + row_mol(meta);
+        pm = pm < p.B ? pm : p.B - 1;
+        const long long nsrc = pm * p.A + row_src(meta), ndst = pm * p.A + row_dst(meta);
+        const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
+        const float ry = p.x[nsrc * 3 + 1] - p.x[ndst * 3 + 1];
+        const float rz = p.x[nsrc * 3 + 2] - p.x[ndst * 3 + 2];
+        const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+        OP g2, tg2;
+        {
+            A16 t1, u1;
+            {
+                OP enc, tenc;
+                {
+                    A16 t, u;
+                    r16::posenc_dual(t, u, dist / p.length_scale, 1.0f / p.length_scale, q);      // seed d|r| = 1
+                    enc.set(t); tenc.set(u);
+                }
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
+                    f32x4 b0 = Z4, b1 = Z4;
+                    r16::gemm_bt2(a0, a1, b0, b1, enc, tenc, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    pipe.release();
+                }
+            }
+            r16::ln_silu_dual(t1, u1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
+            {
+                OP g1, tg1;
+                g1.set(t1); tg1.set(u1);
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
+                    f32x4 b0 = Z4, b1 = Z4;
+                    r16::gemm_bt2(a0, a1, b0, b1, g1, tg1, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    pipe.release();
+                }
+            }
+            r16::ln_silu_dual(t1, u1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
+            g2.set(t1); tg2.set(u1);
+        }
+        f32x4* wq = reinterpret_cast<f32x4*>(p.wq) + ((size_t)(gi * p.nblk + blk) * 5 * NB) * 4 * 64 + lane;
+        auto put = [&](int c, int nbo) {
+            f32x4 b0 = Z4, b1 = Z4, tb0 = Z4, tb1 = Z4;
+            const f32x4* wl = pipe.acquire();
+            r16::gemm_fl2(b0, b1, tb0, tb1, g2, tg2, wl, lane);
+            pipe.release();
+            const float* bw = vec + (EV::W_B2 + c) * F + 32 * nbo + j;
+            if (group_ok) {
+                f32x4* o = wq + (size_t)(c * NB + nbo) * 4 * 64;
+                o[0] = b0 + bw[0]; o[64] = b1 + bw[16]; o[128] = tb0; o[192] = tb1;
+            }
+        };
+#pragma unroll 1
+        for (int nbo = 0; nbo < NB; ++nbo) {          // consumption order of the edge kernels: ds, de, sed, gates, cross gates
+            put(2, nbo);
+            if (!last) put(3, nbo);
+            put(1, nbo);
+            if (!first) { put(0, nbo); put(4, nbo); }
+        }
+        if (p.pad) { (void)pipe.acquire(); pipe.release(); }      // odd chunk count: swallow the pad chunk, stay in phase with the superchunk ring
+    }
+}
+
+// ================================================================================================== tangent edge kernel
+// One wave per virtual group; only the phi branch is differentiated here (see the header).
+template <int NBK, bool SPLIT>
+__global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgeParams p)
+{
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    float* scratch = reinterpret_cast<float*>(lds + 4 * CH4) + wave * 128;         // [16 rows][8]: edge_dir, d|r|', edge_dir', 0
+    float* vec = reinterpret_cast<float*>(lds + 4 * CH4) + WAVES * 128;            // [EV::COUNT][F]
+    for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
+        reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
+    PipeDMA<NB, T, 2> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+
+    const long long gi_raw = (long long)blockIdx.x * WAVES + wave;                 // virtual group
+    const bool group_ok = gi_raw < p.n_groups;
+    const long long gi = group_ok ? gi_raw : p.n_groups - 1;
+    const long long pg = gi / p.D;                                                  // primal group
+    const int dsel = (int)(gi - pg * p.D);                                          // seed direction
+    const bool first = p.first != 0, last = p.last != 0;
+
+    for (int blk = 0; blk < p.nblk; ++blk) {
         // ---- geometry of this lane's row and its tangent
         const uint32_t meta = p.rows[blk * 16 + j];
-        long long vm = gi * p.G + row_mol(meta);
-        vm = vm < p.VB ? vm : p.VB - 1;
-        const long long pm = vm / p.D;
-        const int dsel = (int)(vm - pm * p.D);
+        long long pm = pg * p.G + row_mol(meta);
+        pm = pm < p.B ? pm : p.B - 1;
         const long long nsrc = pm * p.A + row_src(meta), ndst = pm * p.A + row_dst(meta);
-        const int ke = (meta & ROW_VALID) ? blk * 16 + j - row_mol(meta) * p.E : 0;   // sorted edge position inside the molecule
-        const size_t perow = ((size_t)(pm / p.G) * p.nblk) * 16 + (size_t)(pm % p.G) * p.E + ke;   // primal e row
-        const size_t terow0 = ((size_t)gi * p.nblk + blk) * 16;                       // tangent e rows of this block
-        float dist, ddist;
+        const size_t prow0 = ((size_t)pg * p.nblk + blk) * 16;                       // primal rows of this block
+        const size_t trow0 = ((size_t)gi * p.nblk + blk) * 16;                       // tangent rows of this block
         {
             const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
             const float ry = p.x[nsrc * 3 + 1] - p.x[ndst * 3 + 1];
@@ -87,82 +188,46 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
                 const float sg = (float)((row_src(meta) == sa) - (row_dst(meta) == sa));
                 tx = sc == 0 ? sg : 0.f; ty = sc == 1 ? sg : 0.f; tz = sc == 2 ? sg : 0.f;
             }
-            dist = sqrtf(rx * rx + ry * ry + rz * rz);
-            ddist = dist > 0.f ? (rx * tx + ry * ty + rz * tz) / dist : 0.f;
+            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            const float ddist = dist > 0.f ? (rx * tx + ry * ty + rz * tz) / dist : 0.f;
             const float den = 1.0f + dist, k = ddist / (den * den);
             if (q == 0) {
-                *reinterpret_cast<f32x4*>(scratch + j * 8) = f32x4{rx / den, ry / den, rz / den, 0.f};
+                *reinterpret_cast<f32x4*>(scratch + j * 8) = f32x4{rx / den, ry / den, rz / den, ddist};
                 *reinterpret_cast<f32x4*>(scratch + j * 8 + 4) = f32x4{tx / den - rx * k, ty / den - ry * k, tz / den - rz * k, 0.f};
             }
         }
-        // ---- w(enc(d)) hidden layers, activation and tangent
-        OP g2, tg2;
-        {
-            A16 t1, u1;
-            {
-                OP enc, tenc;
-                {
-                    A16 t, u;
-                    r16::posenc_dual(t, u, dist / p.length_scale, ddist / p.length_scale, q);
-                    enc.set(t); tenc.set(u);
-                }
-#pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    const f32x4* wl = pipe.acquire();
-                    f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
-                    f32x4 b0 = Z4, b1 = Z4;
-                    r16::gemm_bt(a0, a1, enc, wl, lane);
-                    r16::gemm_bt(b0, b1, tenc, wl, lane);
-                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
-                    pipe.release();
-                }
-            }
-            r16::ln_silu_dual(t1, u1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
-            {
-                OP g1, tg1;
-                g1.set(t1); tg1.set(u1);
-#pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    const f32x4* wl = pipe.acquire();
-                    f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
-                    f32x4 b0 = Z4, b1 = Z4;
-                    r16::gemm_bt(a0, a1, g1, wl, lane);
-                    r16::gemm_bt(b0, b1, tg1, wl, lane);
-                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
-                    pipe.release();
-                }
-            }
-            r16::ln_silu_dual(t1, u1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
-            g2.set(t1); tg2.set(u1);
-        }
-        // ---- phi([s[src] | e]) hidden layers
+        // ---- phi([s[src] | e]) hidden layers, value and tangent (first layer: s and e do not depend on x, tangent = 0)
         OP h2, th2;
         {
             A16 t1, u1;
             {
                 OP ein, tein;
                 if (first) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
-                else       r16::load_set(t1, p.e + perow * F, q);
+                else       r16::load_set(t1, p.e + (prow0 + j) * F, q);
                 ein.set(t1);
                 if (first) {
 #pragma unroll
                     for (int nb = 0; nb < NBK; ++nb) u1.b[nb] = Z4;
-                } else r16::load_set(u1, p.te + (terow0 + j) * F, q);
+                } else r16::load_set(u1, p.te + (trow0 + j) * F, q);
                 tein.set(u1);
                 const float* prow = p.P + (size_t)nsrc * F;
-                const float* tprow = p.tP + (size_t)(vm * p.A + row_src(meta)) * F;
+                const float* tprow = p.tP + (size_t)((gi * p.G + row_mol(meta)) * p.A + row_src(meta)) * F;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const f32x4* wl = pipe.acquire();
                     f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
-                    f32x4 b0 = r16::load_block(tprow, 2 * c, q), b1 = r16::load_block(tprow, 2 * c + 1, q);
-                    r16::gemm_bt(a0, a1, ein, wl, lane);
-                    r16::gemm_bt(b0, b1, tein, wl, lane);
+                    f32x4 b0 = Z4, b1 = Z4;
+                    if (first) r16::gemm_bt(a0, a1, ein, wl, lane);
+                    else {
+                        b0 = r16::load_block(tprow, 2 * c, q); b1 = r16::load_block(tprow, 2 * c + 1, q);
+                        r16::gemm_bt2(a0, a1, b0, b1, ein, tein, wl, lane);
+                    }
                     t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
                     pipe.release();
                 }
             }
-            r16::ln_silu_dual(t1, u1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
+            if (first) r16::ln_silu(t1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
+            else       r16::ln_silu_dual(t1, u1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
             {
                 OP h1, th1;
                 h1.set(t1); th1.set(u1);
@@ -171,13 +236,14 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
                     const f32x4* wl = pipe.acquire();
                     f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
                     f32x4 b0 = Z4, b1 = Z4;
-                    r16::gemm_bt(a0, a1, h1, wl, lane);
-                    r16::gemm_bt(b0, b1, th1, wl, lane);
+                    if (first) r16::gemm_bt(a0, a1, h1, wl, lane);
+                    else       r16::gemm_bt2(a0, a1, b0, b1, h1, th1, wl, lane);
                     t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
                     pipe.release();
                 }
             }
-            r16::ln_silu_dual(t1, u1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
+            if (first) r16::ln_silu(t1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
+            else       r16::ln_silu_dual(t1, u1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
             h2.set(t1); th2.set(u1);
         }
         // ---- output layer, flipped (features on lanes, the block's rows 4q + r in registers); see painn_edge_kernel
@@ -190,25 +256,30 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
         for (int r = 0; r < 4; ++r) {
             sel[r] = (row_slot(mi[r]) == j) ? 1.0f : 0.0f;
             const int sn = p.slotnode[blk * 16 + 4 * q + r];
-            const long long m2 = gi * p.G + (sn >> 8);
-            snode[r] = (sn >= 0 && group_ok && m2 < p.VB) ? (int)(m2 * p.A + (sn & 255)) : -1;     // TANGENT node
+            const long long m2 = sn >> 8;
+            snode[r] = (sn >= 0 && group_ok && pg * p.G + m2 < p.B) ? (int)((gi * p.G + m2) * p.A + (sn & 255)) : -1;     // TANGENT node
         }
+        f32x4 dir[4], tdir[4], dd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 8);
+            tdir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 8 + 4);
+            dd[r] = dir[r][3];
+        }
+        const f32x4* wq = reinterpret_cast<const f32x4*>(p.wq) + ((size_t)(pg * p.nblk + blk) * 5 * NB) * 4 * 64 + lane;
         // value and tangent of (phi_c + b)(w_c + b) for output chunk c, 32 features as two 16-feature blocks
         auto out_pair = [&](int c, int nbo, f32x4& r0, f32x4& r1, f32x4& d0, f32x4& d1) {
-            f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4, ta0 = Z4, ta1 = Z4, tb0 = Z4, tb1 = Z4;
-            const f32x4* wl0 = pipe.acquire();
-            r16::gemm_fl(a0, a1, h2, wl0, lane);
-            r16::gemm_fl(ta0, ta1, th2, wl0, lane);
-            pipe.release();
-            const f32x4* wl1 = pipe.acquire();
-            r16::gemm_fl(b0, b1, g2, wl1, lane);
-            r16::gemm_fl(tb0, tb1, tg2, wl1, lane);
+            const f32x4* g = wq + (size_t)(c * NB + nbo) * 4 * 64;
+            const f32x4 B0 = g[0], B1 = g[64], Q0 = g[128], Q1 = g[192];
+            f32x4 a0 = Z4, a1 = Z4, ta0 = Z4, ta1 = Z4;
+            const f32x4* wl = pipe.acquire();
+            if (first) r16::gemm_fl(a0, a1, h2, wl, lane);
+            else       r16::gemm_fl2(a0, a1, ta0, ta1, h2, th2, wl, lane);
             pipe.release();
             const float* bp = vec + (EV::P_B2 + c) * F + 32 * nbo + j;
-            const float* bw = vec + (EV::W_B2 + c) * F + 32 * nbo + j;
-            const f32x4 A0 = a0 + bp[0], B0 = b0 + bw[0], A1 = a1 + bp[16], B1 = b1 + bw[16];
+            const f32x4 A0 = a0 + bp[0], A1 = a1 + bp[16];
             r0 = A0 * B0; r1 = A1 * B1;
-            d0 = ta0 * B0 + A0 * tb0; d1 = ta1 * B1 + A1 * tb1;
+            d0 = ta0 * B0 + A0 * (dd * Q0); d1 = ta1 * B1 + A1 * (dd * Q1);
         };
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
             f32x4 s0 = Z4, s1 = Z4;
@@ -232,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
                 out_pair(3, nbo, v0, v1, d0, d1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float* ep = p.te + (terow0 + 4 * q + r) * F + fo;
+                    float* ep = p.te + (trow0 + 4 * q + r) * F + fo;
                     if (group_ok) {
                         if (first) { ep[0] = d0[r]; ep[16] = d1[r]; }
                         else { add_noret(ep, d0[r]); add_noret(ep + 16, d1[r]); }
@@ -246,11 +317,10 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
                 if (!first) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        long long m2 = gi * p.G + row_mol(mi[r]);
-                        m2 = m2 < p.VB ? m2 : p.VB - 1;
-                        const long long pm2 = m2 / p.D;
+                        long long pm2 = pg * p.G + row_mol(mi[r]);
+                        pm2 = pm2 < p.B ? pm2 : p.B - 1;
                         const float* vp = p.v + (size_t)(pm2 * p.A + row_src(mi[r])) * 3 * F + fo;
-                        const float* tp = p.tv + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
+                        const float* tp = p.tv + (size_t)((gi * p.G + row_mol(mi[r])) * p.A + row_src(mi[r])) * 3 * F + fo;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16];
@@ -258,12 +328,6 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
                         }
                     }
                     out_pair(0, nbo, gt0, gt1, tgt0, tgt1);
-                }
-                f32x4 dir[4], tdir[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 8);
-                    tdir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 8 + 4);
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -295,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
                 }
             }
         }
+        if (p.pad) { (void)pipe.acquire(); pipe.release(); }      // odd chunk count: swallow the pad chunk, stay in phase with the superchunk ring
     }
 }
 
@@ -316,10 +381,11 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
     const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;      // virtual node
-    const bool ok = node < p.N;
-    const long long nd = ok ? node : p.N - 1;
-    const long long vm = nd / p.A, pm = vm / p.D;
-    const size_t pn = (size_t)(pm * p.A + (nd - vm * p.A));                          // primal node
+    const long long nd = node < p.N ? node : p.N - 1;
+    const long long vm = nd / p.A, vg = vm / p.G;
+    const long long pm_raw = (vg / p.D) * p.G + (vm - vg * p.G);                      // molecule of this virtual molecule
+    const bool ok = node < p.N && pm_raw < p.B;
+    const size_t pn = (size_t)((pm_raw < p.B ? pm_raw : p.B - 1) * p.A + (nd - vm * p.A));   // primal node
     const float *vb = p.v + pn * 3 * F, *db = p.dvacc + pn * 3 * F, *cb = p.cacc + pn * 3 * F, *sb = p.s + pn * F, *ab = p.dsacc + pn * F;
     float *tvb = p.tv + (size_t)nd * 3 * F, *tdb = p.tdvacc + (size_t)nd * 3 * F, *tcb = p.tcacc + (size_t)nd * 3 * F;
     float *tsb = p.ts + (size_t)nd * F, *tab = p.tdsacc + (size_t)nd * F;
@@ -358,8 +424,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4;
-            r16::gemm_bt(a0, a1, ve, wl, lane);
-            r16::gemm_bt(b0, b1, tve, wl, lane);
+            r16::gemm_bt2(a0, a1, b0, b1, ve, tve, wl, lane);
             n2.b[2 * ch] += a0 * a0; n2.b[2 * ch + 1] += a1 * a1;
             nd2.b[2 * ch] += a0 * b0; nd2.b[2 * ch + 1] += a1 * b1;
             pipe.release();
@@ -386,8 +451,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
-                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], nn, wl, lane);
-                r16::gemm_bt(u.b[2 * ch], u.b[2 * ch + 1], tnn, wl, lane);
+                r16::gemm_bt2(t.b[2 * ch], t.b[2 * ch + 1], u.b[2 * ch], u.b[2 * ch + 1], nn, tnn, wl, lane);
                 pipe.release();
             }
         }
@@ -405,8 +469,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
-                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], ss, wl, lane);
-                r16::gemm_bt(u.b[2 * ch], u.b[2 * ch + 1], tss, wl, lane);
+                r16::gemm_bt2(t.b[2 * ch], t.b[2 * ch + 1], u.b[2 * ch], u.b[2 * ch + 1], ss, tss, wl, lane);
                 pipe.release();
             }
         }
@@ -419,8 +482,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
                 const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(vec + UV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B1 * F, 2 * ch + 1, q);
                 f32x4 b0 = Z4, b1 = Z4;
-                r16::gemm_bt(a0, a1, h1, wl, lane);
-                r16::gemm_bt(b0, b1, th1, wl, lane);
+                r16::gemm_bt2(a0, a1, b0, b1, h1, th1, wl, lane);
                 t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
                 pipe.release();
             }
@@ -434,8 +496,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
         const f32x4* wl = pipe.acquire();
         f32x4 q0 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch, q), q1 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch + 1, q);
         f32x4 tq0 = Z4, tq1 = Z4;
-        r16::gemm_bt(q0, q1, h2, wl, lane);
-        r16::gemm_bt(tq0, tq1, th2, wl, lane);
+        r16::gemm_bt2(q0, q1, tq0, tq1, h2, th2, wl, lane);
         pipe.release();
         wl = pipe.acquire();
         f32x4 ta0 = Z4, ta1 = Z4;                      // the primal `add` term does not enter any tangent
@@ -463,8 +524,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
         const f32x4* wl = pipe.acquire();
         f32x4 a0 = r16::load_block(vec + UV::B2 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B2 * F, 2 * ch + 1, q);
         f32x4 b0 = Z4, b1 = Z4;
-        r16::gemm_bt(a0, a1, h2, wl, lane);
-        r16::gemm_bt(b0, b1, th2, wl, lane);
+        r16::gemm_bt2(a0, a1, b0, b1, h2, th2, wl, lane);
         gg.b[2 * ch] = a0; gg.b[2 * ch + 1] = a1; tgg.b[2 * ch] = b0; tgg.b[2 * ch + 1] = b1;
         pipe.release();
     }
@@ -489,8 +549,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4;
-            r16::gemm_bt(a0, a1, ve, wl, lane);
-            r16::gemm_bt(b0, b1, tve, wl, lane);
+            r16::gemm_bt2(a0, a1, b0, b1, ve, tve, wl, lane);
             pipe.release();
             const f32x4 e0 = r16::load_block(tdb + c * F, 2 * ch, q), e1 = r16::load_block(tdb + c * F, 2 * ch + 1, q);
             if (ok) {
@@ -542,11 +601,12 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
     PipeDMA<NB, T, 2> pipe;
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
-    const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
-    const bool ok = node < p.N;
-    const long long nd = ok ? node : p.N - 1;
-    const long long vm = nd / p.A, pm = vm / p.D;
-    const size_t pn = (size_t)(pm * p.A + (nd - vm * p.A));
+    const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;      // virtual node
+    const long long nd = node < p.N ? node : p.N - 1;
+    const long long vm = nd / p.A, vg = vm / p.G;
+    const long long pm_raw = (vg / p.D) * p.G + (vm - vg * p.G);                      // molecule of this virtual molecule
+    const bool ok = node < p.N && pm_raw < p.B;
+    const size_t pn = (size_t)((pm_raw < p.B ? pm_raw : p.B - 1) * p.A + (nd - vm * p.A));   // primal node
 
     A16 t, u;
     {
@@ -562,8 +622,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = r16::load_block(vec + RV::B0 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B0 * F, 2 * ch + 1, q);
             f32x4 b0 = Z4, b1 = Z4;
-            r16::gemm_bt(a0, a1, ss, wl, lane);
-            r16::gemm_bt(b0, b1, tss, wl, lane);
+            r16::gemm_bt2(a0, a1, b0, b1, ss, tss, wl, lane);
             t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
             pipe.release();
         }
@@ -577,8 +636,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = r16::load_block(vec + RV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B1 * F, 2 * ch + 1, q);
             f32x4 b0 = Z4, b1 = Z4;
-            r16::gemm_bt(a0, a1, h1, wl, lane);
-            r16::gemm_bt(b0, b1, th1, wl, lane);
+            r16::gemm_bt2(a0, a1, b0, b1, h1, th1, wl, lane);
             t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
             pipe.release();
         }
@@ -608,13 +666,15 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
     }
 }
 
-// div[b] = sum_d tout[b*D + d][d]  (unit seeds: direction d = 3 atom + component is also the flat index inside [A][3])
-__global__ void painn_div_reduce_kernel(const float* __restrict__ tout, long long B, int D, float* __restrict__ div)
+// div[b] = sum_d tangent[(virtual molecule of (b, d))][d]  (unit seeds: direction d = 3 atom + component is also the flat
+// index inside [A][3]); fixed summation order
+__global__ void painn_div_reduce_kernel(const float* __restrict__ tout, long long B, int D, int G, float* __restrict__ div)
 {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const long long pg = b / G, m = b - pg * G;
     float acc = 0.f;
-    for (int d = 0; d < D; ++d) acc += tout[((size_t)b * D + d) * D + d];
+    for (int d = 0; d < D; ++d) acc += tout[(size_t)(((pg * D + d) * G + m)) * D + d];
     div[b] = acc;
 }
 
@@ -646,6 +706,8 @@ template <int NBK>
 static hipError_t configure_jvp_nbk(int NB)
 {
     hipError_t e;
+    if ((e = set_lds(painn_jvp_filter_kernel<NBK, false>, jvp_node_lds(NB, EV::COUNT))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_filter_kernel<NBK, true>, jvp_node_lds(NB, EV::COUNT))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_edge_kernel<NBK, false>, jvp_edge_lds(NB))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_edge_kernel<NBK, true>, jvp_edge_lds(NB))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_update_kernel<NBK, false>, jvp_node_lds(NB, UV::COUNT))) != hipSuccess) return e;
@@ -659,6 +721,17 @@ hipError_t configure_painn_jvp_kernels(int NBv)
 {
     TI_JVP_DISPATCH(NBv, return configure_jvp_nbk<NBK>(NBv));
     return hipSuccess;
+}
+
+hipError_t launch_jvp_filter(int NBv, bool split, const JvpFilterParams& p, hipStream_t st)
+{
+    const dim3 g((unsigned)((p.n_groups + 3) / 4));
+    const size_t l = jvp_node_lds(NBv, EV::COUNT);
+    TI_JVP_DISPATCH(NBv, {
+        if (split) hipLaunchKernelGGL((painn_jvp_filter_kernel<NBK, true>), g, dim3(256), l, st, p);
+        else hipLaunchKernelGGL((painn_jvp_filter_kernel<NBK, false>), g, dim3(256), l, st, p);
+    });
+    return hipGetLastError();
 }
 
 hipError_t launch_jvp_edge(int NBv, bool split, const JvpEdgeParams& p, hipStream_t st)
@@ -694,9 +767,9 @@ hipError_t launch_jvp_readout(int NBv, bool split, const JvpReadoutParams& p, hi
     return hipGetLastError();
 }
 
-hipError_t launch_div_reduce(const float* tout, long long B, int D, float* div, hipStream_t st)
+hipError_t launch_div_reduce(const float* tout, long long B, int D, int G, float* div, hipStream_t st)
 {
-    hipLaunchKernelGGL(painn_div_reduce_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, tout, B, D, div);
+    hipLaunchKernelGGL(painn_div_reduce_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, tout, B, D, G, div);
     return hipGetLastError();
 }
 

@@ -122,8 +122,8 @@ struct ti_handle {
     DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs, upd_vecs;
     int tap = -1; long long last_B = 0;
     // forward-mode derivative (painn_jvp_kernels.hip): tangent twins over virtual molecules, sized on first use
-    std::vector<Stream> st_jvp_update; Stream st_jvp_readout{};
-    DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, divb, dl, dlscaled, div2;
+    std::vector<Stream> st_jvp_update, st_jvp_w, st_jvp_phi; Stream st_jvp_readout{}; std::vector<int> jvp_w_pad, jvp_phi_pad;
+    DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, wq, divb, dl, dlscaled, div2;
     long long jvp_cap = 0, last_VB = 0; int last_D = 1;
 
     // ---- adw
@@ -253,6 +253,23 @@ void pack_painn(ti_handle* h, const float* wts)
         if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);                            // phase D
         pad_even(o);                                                                  // whole superchunks
         h->st_update.push_back(end_stream(o));
+        // tangent kernels (painn_jvp_kernels.hip): the filter branch and the phi branch as separate streams, same chunk order
+        for (int which = 0; which < 2; ++which) {
+            const MlpOff& m = which == 0 ? h->w[l] : h->phi[l];
+            o = begin_stream();
+            if (which == 0) layer16(m.W0, F, F, 0); else layer16(m.W0, 2 * F, F, F);
+            layer16(m.W1, F, F, 0);
+            for (int nbo = 0; nbo < NB; ++nbo)
+                for (int c : {2, 3, 1, 0, 4}) {
+                    if (c == 3 && last) continue;
+                    if ((c == 0 || c == 4) && first) continue;
+                    chunk16(m.W2, F, 5 * F, c * F + 32 * nbo, 0);
+                }
+            const int real = end_stream(o).nch;   // an odd count gets one pad chunk, which the kernels swallow once per row block
+            pad_even(o);
+            (which == 0 ? h->st_jvp_w : h->st_jvp_phi).push_back(end_stream(o));
+            if (which == 0) h->jvp_w_pad.push_back(real & 1); else h->jvp_phi_pad.push_back(real & 1);
+        }
         o = begin_stream();                          // tangent update kernel: same order, V and U once per spatial component
         for (int c = 0; c < 3; ++c) layer16(h->V[l], F, F, 0);
         layer16(h->upd[l].W0, 2 * F, F, 0); layer16(h->upd[l].W0, 2 * F, F, F);
@@ -316,7 +333,9 @@ void ensure_painn_ws(ti_handle* h, long long B)
     h->cap = B;
 }
 
-// ---- forward-mode derivative: tangent workspace over VB virtual molecules (ti_internal.hpp: JvpEdgeParams)
+// ---- forward-mode derivative: tangent workspace over ceil(B/G)*D*G virtual molecules (painn_jvp_kernels.hip header)
+long long jvp_virtual_molecules(const ti_handle* h, long long B, int D) { return (B + h->G - 1) / h->G * D * h->G; }
+
 size_t jvp_bytes_per_vm(const ti_handle* h)
 {
     const size_t A = h->d.n_atoms, F = h->d.n_features;
@@ -324,12 +343,16 @@ size_t jvp_bytes_per_vm(const ti_handle* h)
     return (A * F * 12 + erows * F + A * 3) * sizeof(float);
 }
 
-void ensure_jvp_ws(ti_handle* h, long long VB)
+void ensure_jvp_ws(ti_handle* h, long long B, int D)
 {
-    if (VB <= h->jvp_cap) return;
+    const long long VB = jvp_virtual_molecules(h, B, D);
     const size_t A = h->d.n_atoms, F = h->d.n_features, N = (size_t)VB * A;
+    const size_t pgroups = ((size_t)B + h->G - 1) / h->G;
+    const size_t wq_floats = std::max<size_t>(pgroups * h->nblk * 5 * h->NB * 4 * 64 * 4, 4);
+    if (h->wq.n < wq_floats) h->wq.alloc(wq_floats);
+    if (VB <= h->jvp_cap) return;
     if (N >= ((size_t)1 << 31)) throw std::invalid_argument("too many tangent nodes in one pass (lower TI_JVP_WS_GB)");
-    const size_t groups = ((size_t)VB + h->G - 1) / h->G;
+    const size_t groups = (size_t)VB / h->G;
     h->ts.alloc(N * F); h->tP.alloc(N * F); h->tdsacc.alloc(N * F);
     h->tv.alloc(N * 3 * F); h->tdvacc.alloc(N * 3 * F); h->tcacc.alloc(N * 3 * F);
     h->te.alloc(std::max<size_t>(groups * h->nblk * ti::EDGE_ROWS_PER_BLOCK * F, 1));
@@ -344,8 +367,9 @@ long long jvp_chunk_molecules(const ti_handle* h, int D)
     if (const char* e = std::getenv("TI_JVP_WS_GB")) gb = std::max(0.001, std::atof(e));
     const double per_mol = (double)jvp_bytes_per_vm(h) * D;
     const long long by_mem = (long long)(gb * 1e9 / per_mol);
-    const long long by_index = (long long)(((size_t)1 << 31) - 1) / ((long long)D * h->d.n_atoms);
-    return std::max<long long>(1, std::min(by_mem, by_index));
+    const long long by_index = (long long)(((size_t)1 << 31) - 1) / ((long long)D * h->d.n_atoms) - h->G;
+    const long long c = std::max<long long>(1, std::min(by_mem, by_index));
+    return c >= h->G ? c / h->G * h->G : c;                  // whole primal groups per pass
 }
 
 struct JvpRun {            // one tangent pass riding on a drift evaluation
@@ -363,10 +387,10 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     const long long N = B * A, groups = (B + h->G - 1) / h->G;
     hipStream_t st = h->stream;
     const bool split = h->d.precision == TI_PREC_F16X2;
-    const long long VB = jr ? B * jr->D : 0, VN = VB * A, vgroups = (VB + h->G - 1) / h->G;
+    const long long VB = jr ? jvp_virtual_molecules(h, B, jr->D) : 0, VN = VB * A, vgroups = VB / h->G;
     if (jr) {
-        ensure_jvp_ws(h, VB);
-        h->last_VB = VB; h->last_D = jr->D;
+        ensure_jvp_ws(h, B, jr->D);
+        h->last_VB = B * jr->D; h->last_D = jr->D;
         const size_t nb = (size_t)VN * F * sizeof(float);
         HIP_CHECK(hipMemsetAsync(h->ts.p, 0, nb, st)); HIP_CHECK(hipMemsetAsync(h->tP.p, 0, nb, st));
         HIP_CHECK(hipMemsetAsync(h->tdsacc.p, 0, nb, st));
@@ -392,12 +416,22 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     if (h->tap == 0) return;
     for (int l = 0; l < L; ++l) {
         if (jr && h->nblk > 0) {
+            {
+                JvpFilterParams p{};
+                p.stream = h->S(h->st_jvp_w[l]); p.nch = h->st_jvp_w[l].nch; p.pad = h->jvp_w_pad[l]; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
+                p.rows = h->rows.p; p.nblk = h->nblk; p.G = h->G; p.A = A; p.first = l == 0; p.last = l == L - 1;
+                p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale; p.x = x_dev;
+                p.wq = reinterpret_cast<float4*>(h->wq.p);
+                Timed tm(h, TI_KERNEL_PAINN_JVP_FILTER);
+                HIP_CHECK(launch_jvp_filter(NB, split, p, st));
+            }
             JvpEdgeParams p{};
-            p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
+            p.stream = h->S(h->st_jvp_phi[l]); p.nch = h->st_jvp_phi[l].nch; p.pad = h->jvp_phi_pad[l]; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
             p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p;
-            p.nblk = h->nblk; p.G = h->G; p.A = A; p.E = h->d.n_edges; p.D = jr->D; p.first = l == 0; p.last = l == L - 1;
-            p.B = B; p.VB = VB; p.n_groups = vgroups; p.length_scale = h->d.length_scale;
-            p.x = x_dev; p.xdot = jr->xdot; p.P = h->P.p; p.v = h->v.p; p.e = h->e.p; p.tP = h->tP.p; p.tv = h->tv.p;
+            p.nblk = h->nblk; p.G = h->G; p.A = A; p.D = jr->D; p.first = l == 0; p.last = l == L - 1;
+            p.B = B; p.n_groups = vgroups;
+            p.x = x_dev; p.xdot = jr->xdot; p.P = h->P.p; p.v = h->v.p; p.e = h->e.p; p.wq = reinterpret_cast<const float4*>(h->wq.p);
+            p.tP = h->tP.p; p.tv = h->tv.p;
             p.te = h->te.p; p.tdsacc = h->tdsacc.p; p.tdvacc = h->tdvacc.p; p.tcacc = h->tcacc.p;
             Timed tm(h, TI_KERNEL_PAINN_JVP_EDGE);
             HIP_CHECK(launch_jvp_edge(NB, split, p, st));
@@ -415,7 +449,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         if (jr) {
             JvpUpdateParams p{};
             p.stream = h->S(h->st_jvp_update[l]); p.nch = h->st_jvp_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
-            p.N = VN; p.A = A; p.D = jr->D; p.has_next = l + 1 < L;
+            p.N = VN; p.B = B; p.A = A; p.D = jr->D; p.G = h->G; p.has_next = l + 1 < L;
             p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p;
             p.ts = h->ts.p; p.tv = h->tv.p; p.tdsacc = h->tdsacc.p; p.tdvacc = h->tdvacc.p; p.tcacc = h->tcacc.p; p.tP = h->tP.p;
             Timed tm(h, TI_KERNEL_PAINN_JVP_UPDATE);
@@ -433,7 +467,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     if (jr) {
         JvpReadoutParams p{};
         p.stream = h->S(h->st_jvp_readout); p.nch = h->st_jvp_readout.nch; p.vecs = h->jvp_ro_vecs.p; p.b2_gate = h->b2_gate;
-        p.N = VN; p.A = A; p.D = jr->D; p.s = h->s.p; p.v = h->v.p; p.ts = h->ts.p; p.tv = h->tv.p; p.tout = jr->tout;
+        p.N = VN; p.B = B; p.A = A; p.D = jr->D; p.G = h->G; p.s = h->s.p; p.v = h->v.p; p.ts = h->ts.p; p.tv = h->tv.p; p.tout = jr->tout;
         Timed tm(h, TI_KERNEL_PAINN_JVP_READOUT);
         HIP_CHECK(launch_jvp_readout(NB, split, p, st));
     }
@@ -454,11 +488,11 @@ void painn_drift_div_dev(ti_handle* h, const float* x_dev, float t, const float*
     const long long chunk = jvp_chunk_molecules(h, D);
     for (long long b0 = 0; b0 < B; b0 += chunk) {
         const long long bc = std::min(chunk, B - b0);
-        ensure_jvp_ws(h, bc * D);
+        ensure_jvp_ws(h, bc, D);
         JvpRun jr{D, nullptr, h->tout.p};
         painn_drift_dev(h, x_dev + (size_t)b0 * A * 3, t, cond_dev ? cond_dev + (size_t)b0 * A * h->ncond : nullptr, bc,
                         out_dev + (size_t)b0 * A * 3, &jr);
-        HIP_CHECK(launch_div_reduce(h->tout.p, bc, D, div_dev + b0, h->stream));
+        HIP_CHECK(launch_div_reduce(h->tout.p, bc, D, h->G, div_dev + b0, h->stream));
     }
     h->last_B = std::min(chunk, B);
 }
@@ -741,7 +775,7 @@ int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t,
     return guarded([&]() -> int {
         set_device(h);
         ensure_painn_ws(h, B);
-        ensure_jvp_ws(h, B);
+        ensure_jvp_ws(h, B, 1);
         const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
         const float *xd = x, *td = xdot, *cd = cond; float *od = out, *otd = out_tan;
         if (mem == TI_MEM_HOST) {

@@ -75,36 +75,46 @@ hipError_t launch_update(int NB, bool has_next, bool split, const UpdateParams& 
 hipError_t launch_readout(int NB, const ReadoutParams& p, hipStream_t st);
 hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
 
-// ---- forward-mode derivative of the drift (painn_jvp_kernels.hip).  Virtual molecule vm = b*D + d: molecule b, seed
-// direction d.  D = 3A and xdot == NULL: unit seeds (d -> atom d/3, component d%3); D = 1 with xdot [B*A][3]: that direction.
-// Tangent arrays are laid out like their primal twins over VB = B*D virtual molecules; primal arrays are read only.
-struct JvpEdgeParams {
-    const float4* stream; int nch; const float* vecs; const float* edge_emb;
-    const uint32_t* rows; const int32_t* slotnode;
-    int nblk, G, A, E, D, first, last;
-    long long B, VB, n_groups;              // molecules, virtual molecules, groups of G virtual molecules
+// ---- forward-mode derivative of the drift (painn_jvp_kernels.hip; virtual-molecule layout described there).
+// D = 3A and xdot == NULL: unit seeds (direction d -> atom d/3, component d%3); D = 1 with xdot [B*A][3]: that direction.
+// Tangent arrays are laid out like their primal twins over ceil(B/G)*D*G virtual molecules; primal arrays are read only.
+struct JvpFilterParams {                    // w_o and d w_o / d|r| of every primal edge of one layer
+    const float4* stream; int nch, pad; const float* vecs;      // pad: the stream ends with one pad chunk per row block
+    const uint32_t* rows;
+    int nblk, G, A, first, last;
+    long long B, n_groups;                  // molecules, primal groups
     float length_scale;
+    const float* x;
+    float4* wq;                             // [n_groups*nblk][5][NB][4][64] float4
+};
+struct JvpEdgeParams {
+    const float4* stream; int nch, pad; const float* vecs; const float* edge_emb;
+    const uint32_t* rows; const int32_t* slotnode;
+    int nblk, G, A, D, first, last;
+    long long B, n_groups;                  // molecules, VIRTUAL groups (= primal groups * D)
     const float *x, *xdot;
     const float *P, *v, *e;                 // primal state entering this layer's message block
+    const float4* wq;                       // filter pass output of this layer
     const float *tP, *tv;                   // tangents of P and v
     float *te, *tdsacc, *tdvacc, *tcacc;    // tangent of e (updated in place), tangent accumulators (+=)
 };
 struct JvpUpdateParams {
     const float4* stream; int nch; const float* vecs;
-    long long N; int A, D, has_next;        // N = VB*A virtual nodes
+    long long N, B; int A, D, G, has_next;  // N virtual nodes
     const float *s, *v, *dsacc, *dvacc, *cacc;                  // primal, as the primal edge kernel left them
     float *ts, *tv, *tdsacc, *tdvacc, *tcacc, *tP;
 };
 struct JvpReadoutParams {
     const float4* stream; int nch; const float* vecs; float b2_gate;      // vecs: b0 g0 be0 b1 g1 be1 w2_gate Vr (x F)
-    long long N; int A, D;
+    long long N, B; int A, D, G;
     const float *s, *v, *ts, *tv;
-    float* tout;                            // [VB*A][3]
+    float* tout;                            // [virtual nodes][3]
 };
+hipError_t launch_jvp_filter(int NB, bool split, const JvpFilterParams& p, hipStream_t st);
 hipError_t launch_jvp_edge(int NB, bool split, const JvpEdgeParams& p, hipStream_t st);
 hipError_t launch_jvp_update(int NB, bool split, const JvpUpdateParams& p, hipStream_t st);
 hipError_t launch_jvp_readout(int NB, bool split, const JvpReadoutParams& p, hipStream_t st);
-hipError_t launch_div_reduce(const float* tout, long long B, int D, float* div, hipStream_t st);
+hipError_t launch_div_reduce(const float* tout, long long B, int D, int G, float* div, hipStream_t st);
 hipError_t configure_painn_jvp_kernels(int NB);
 
 // ---- adw (adw_kernels.hip).  One kernel evaluates  Linear(3->H), SiLU, [Linear(H->H), SiLU] x n_hidden, Linear(H->1)
