@@ -13,6 +13,8 @@
  *                                     + ODEWrapper.forward/reset_batch     mdqm9/thermo/{ambient,latent}/models/ode_wrapper.py
  *   ti_painn_rollout                  MoleculeIntegrator.rollout           mdqm9/thermo/ambient/integrators.py:28-68
  *                                                                          mdqm9/thermo/latent/integrators.py:41-89
+ *   ti_painn_drift_div / _jvp         ODEWrapper.compute_divergence        mdqm9/thermo/{ambient,latent}/models/ode_wrapper.py:59-91
+ *   ti_painn_rollout_dlogp            MoleculeIntegrator.rollout(return_dlogp=True), ODEWrapper.forward (b, -div)
  *
  * Conventions
  *   - Plain pointers and sizes only; no exceptions cross the ABI.  Every int-returning call returns TI_OK (0) or a
