@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TI_ABI_VERSION 1
+#define TI_ABI_VERSION 2
 
 enum { TI_OK = 0, TI_E_ARG = -1, TI_E_HIP = -2, TI_E_NAN = -3, TI_E_ALLOC = -4, TI_E_UNSUPPORTED = -5 };
 enum { TI_MEM_HOST = 0, TI_MEM_DEVICE = 1 };
@@ -60,7 +60,15 @@ enum { TI_PREC_F32 = 0, TI_PREC_F16X2 = 1 };
  *   HEUN : xp = x_k + dt_k b(x_k,t_k); x_{k+1} = x_k + dt_k/2 (b(x_k,t_k) + b(xp,t_{k+1}))
  *   EM   : x_{k+1} = x_k + dt_k b(x_k,t_k) + sqrt(2 eps |dt_k|) xi,  xi ~ N(0,1) from Philox4x32-10 keyed by
  *          (seed, global trajectory id, step, component); eps = 0 reproduces EULER bit-for-bit. */
-enum { TI_SCHEME_EULER = 0, TI_SCHEME_HEUN = 1, TI_SCHEME_EM = 2 };
+enum { TI_SCHEME_EULER = 0, TI_SCHEME_HEUN = 1, TI_SCHEME_EM = 2,
+       /* torchdiffeq 0.2.5 solvers (the reference's integrator library, ti_env.yml:14; third-party, restated from its published
+        * algorithm -- parity unpinned):
+        *   DOPRI5   : adaptive Dormand-Prince 5(4) with FSAL, step control err = rms((y1_err)/(atol + rtol max(|y0|,|y1|))) <= 1
+        *              (two-state runs: max of the per-state rms), factor = min(10, max(0.9 err^(-1/5), 0.2 | 1)), initial step
+        *              by Hairer's rule, quartic dense output evaluated at the grid times (the grid only selects output times);
+        *   MIDPOINT : fixed grid, y += dt f(t + dt/2, y + dt/2 f(t, y));
+        *   RK4      : fixed grid, the 3/8-rule (torchdiffeq's `rk4`). */
+       TI_SCHEME_DOPRI5 = 3, TI_SCHEME_MIDPOINT = 4, TI_SCHEME_RK4 = 5 };
 
 typedef struct ti_handle ti_handle;
 
@@ -97,6 +105,7 @@ typedef struct ti_rollout_desc {
     uint64_t seed;          /* EM Philox key */
     int64_t traj_offset;    /* global index of trajectory 0 of this call (multi-GPU shards keep RNG independent of the split) */
     const float* t_grid;    /* [n_step] host memory */
+    float   rtol, atol;     /* DOPRI5 tolerances (> 0); ignored by the fixed-grid schemes */
 } ti_rollout_desc;
 
 /* number of path rows ti_*_rollout writes for (n_step, save_every) */

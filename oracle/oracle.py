@@ -30,7 +30,7 @@ class AdwDesc(C.Structure):
 class RolloutDesc(C.Structure):
     _fields_ = [("scheme", C.c_int32), ("n_step", C.c_int32), ("save_every", C.c_int32), ("mem", C.c_int32),
                 ("eps", C.c_float), ("com_free_noise", C.c_int32), ("seed", C.c_uint64), ("traj_offset", C.c_int64),
-                ("t_grid", C.POINTER(C.c_float))]
+                ("t_grid", C.POINTER(C.c_float)), ("rtol", C.c_float), ("atol", C.c_float)]
 
 
 SCHEMES = {"euler": 0, "heun": 1, "em": 2}
@@ -77,7 +77,7 @@ def rollout_rows(n_step: int, save_every: int) -> int:
 def make_rollout_desc(scheme, t_grid, save_every=1, eps=0.0, seed=0, traj_offset=0, com_free_noise=0):
     t_grid = f32(t_grid)
     rd = RolloutDesc(SCHEMES[scheme] if isinstance(scheme, str) else scheme, len(t_grid), save_every, 0, eps, com_free_noise,
-                     seed, traj_offset, _p(t_grid, C.c_float))
+                     seed, traj_offset, _p(t_grid, C.c_float), 0.0, 0.0)
     rd._keep = t_grid
     return rd
 

@@ -104,8 +104,9 @@ def test_api_mirror_signatures_and_solver_names():
     for cls in (amb.MoleculeIntegrator, lat.MoleculeIntegrator):
         integ = cls(b=b, method="heun", rtol=1e-5, atol=1e-5, n_step=100, return_dlogp=False, reverse_ode=False)
         assert integ.n_step == 100
+        assert cls(b=b, n_step=10).method == "dopri5"                  # the reference default is built (restated torchdiffeq 0.2.5)
         with pytest.raises(NotImplementedError, match="torchdiffeq"):
-            cls(b=b, method="dopri5", n_step=10)
+            cls(b=b, method="dopri8", n_step=10)
         assert cls(b=b, method="euler", n_step=10, return_dlogp=True, reverse_ode=True).return_dlogp       # exact divergence: built
         with pytest.raises(ValueError, match="deterministic"):
             cls(b=b, method="em", n_step=10, return_dlogp=True, eps=0.1)
@@ -116,8 +117,9 @@ def test_api_mirror_signatures_and_solver_names():
     net.load_state_dict({k[4:]: v for k, v in g.items() if k.startswith("sd::")})
     assert net.state_dict()["net.0.weight"].shape == (64, 3)
     adw.StandardIntegrator(b=net, method="euler", rtol=1e-4, atol=1e-4, n_step=400, return_dlogp=False)
+    assert adw.StandardIntegrator(b=net, n_step=400).method == "dopri5"
     with pytest.raises(NotImplementedError):
-        adw.StandardIntegrator(b=net, method="dopri5", n_step=400)
+        adw.StandardIntegrator(b=net, method="bosh3", n_step=400)
     with pytest.raises(NotImplementedError):
         adw.FCNetMultiBeta(2, 2, 64, 3)
 

@@ -15,7 +15,7 @@ SO_PATH = os.path.join(HERE, "libti_hip.so")
 
 TI_OK, TI_E_ARG, TI_E_HIP, TI_E_NAN, TI_E_ALLOC, TI_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
-SCHEMES = {"euler": 0, "heun": 1, "em": 2}
+SCHEMES = {"euler": 0, "heun": 1, "em": 2, "dopri5": 3, "midpoint": 4, "rk4": 5}
 PRECISIONS = {"f32": 0, "f16x2": 1}
 KERNELS = {"painn_edge": 0, "painn_update": 1, "painn_embed": 2, "painn_readout": 3, "adw": 4, "integrate": 5,
            "painn_jvp_edge": 6, "painn_jvp_update": 7, "painn_jvp_readout": 8, "painn_jvp_filter": 9}
@@ -43,7 +43,7 @@ class AdwDesc(C.Structure):
 class RolloutDesc(C.Structure):
     _fields_ = [("scheme", C.c_int32), ("n_step", C.c_int32), ("save_every", C.c_int32), ("mem", C.c_int32),
                 ("eps", C.c_float), ("com_free_noise", C.c_int32), ("seed", C.c_uint64), ("traj_offset", C.c_int64),
-                ("t_grid", C.POINTER(C.c_float))]
+                ("t_grid", C.POINTER(C.c_float)), ("rtol", C.c_float), ("atol", C.c_float)]
 
 
 class TiError(RuntimeError):

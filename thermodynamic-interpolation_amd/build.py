@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libti_hip.so")
-SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_jvp_kernels.hip", "adw_kernels.hip"]
+SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
 HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

@@ -125,6 +125,8 @@ struct ti_handle {
     std::vector<Stream> st_jvp_update, st_jvp_w, st_jvp_phi; Stream st_jvp_readout{}; std::vector<int> jvp_w_pad, jvp_phi_pad;
     DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, wq, divb, dl, dlscaled, div2;
     long long jvp_cap = 0, last_VB = 0; int last_D = 1;
+    // Runge-Kutta drivers (rollout_rk): stage derivatives, dense-output coefficients, reduction scratch
+    DevBuf<float> rk_ws; DevBuf<double> rk_red;
 
     // ---- adw
     ti_adw_desc ad{};
@@ -604,11 +606,182 @@ int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1,
     return flag ? fail(TI_E_NAN, "non-finite value in the final state") : TI_OK;
 }
 
+// ---- Runge-Kutta drivers on top of the same drift callback: torchdiffeq 0.2.5's `dopri5` (adaptive), `midpoint`, `rk4`
+// (include/ti_hip.h TI_SCHEME_*).  State = segment 0 (x, n floats) and optionally segment 1 (dlogp, aux.n_dl floats) with
+// right-hand side (b, -div_scale * div); a decreasing grid is integrated in s = -t with f'(s, y) = -f(-s, y) like
+// torchdiffeq's _ReverseFunc.  Times and step sizes are fp64 on the host and enter state arithmetic as fp32, as there.
+namespace dp5 {
+constexpr double alpha[6] = {1. / 5, 3. / 10, 4. / 5, 8. / 9, 1., 1.};
+constexpr double beta[6][6] = {{1. / 5},
+                               {3. / 40, 9. / 40},
+                               {44. / 45, -56. / 15, 32. / 9},
+                               {19372. / 6561, -25360. / 2187, 64448. / 6561, -212. / 729},
+                               {9017. / 3168, -355. / 33, 46732. / 5247, 49. / 176, -5103. / 18656},
+                               {35. / 384, 0., 500. / 1113, 125. / 192, -2187. / 6784, 11. / 84}};
+constexpr double c_error[7] = {35. / 384 - 1951. / 21600, 0., 500. / 1113 - 22642. / 50085, 125. / 192 - 451. / 720,
+                               -2187. / 6784 - -12231. / 42400, 11. / 84 - 649. / 6300, -1. / 60};
+constexpr double c_mid[7] = {6025192743. / 30085553152. / 2, 0., 51252292925. / 65400821598. / 2, -2691868925. / 45128329728. / 2,
+                             187940372067. / 1594534317056. / 2, -1776094331. / 19743644256. / 2, 11237099. / 235043384. / 2};
+}  // namespace dp5
+
+template <typename Drift>
+int rollout_rk(ti_handle* h, const ti_rollout_desc* rd, float* x, size_t n, float* out_path, int64_t* n_fevals, Drift&& drift,
+               DlogpAux aux = DlogpAux())
+{
+    hipStream_t st = h->stream;
+    const hipMemcpyKind out_kind = rd->mem == TI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const int nseg = aux.dl ? 2 : 1;
+    const size_t ndl = aux.dl ? (aux.n_dl ? aux.n_dl : n) : 0;
+    const size_t sn[2] = {n, ndl};
+    // workspace: per segment k[7], ytmp, ynew, coef[5]
+    const size_t per = 14;
+    if (h->rk_ws.n < per * (n + ndl)) h->rk_ws.alloc(per * (n + ndl));
+    if (h->rk_red.n < (size_t)RED_PARTIALS + 8) h->rk_red.alloc(RED_PARTIALS + 8);
+    float* y[2] = {x, aux.dl};
+    float *k[2][7] = {}, *ytmp[2] = {}, *ynew[2] = {}, *coef[2] = {};
+    struct Pair { float* p[2]; operator float* const*() const { return p; } };
+    auto KP = [&](int j) { return Pair{{k[0][j], k[1][j]}}; };
+    {
+        float* w = h->rk_ws.p;
+        for (int s2 = 0; s2 < nseg; ++s2) {
+            for (int j = 0; j < 7; ++j) { k[s2][j] = w; w += sn[s2]; }
+            ytmp[s2] = w; w += sn[s2]; ynew[s2] = w; w += sn[s2]; coef[s2] = w; w += 5 * sn[s2];
+        }
+    }
+    if (aux.dl) HIP_CHECK(hipMemsetAsync(aux.dl, 0, ndl * sizeof(float), st));
+    const int N = rd->n_step;
+    const double sign = (N > 1 && rd->t_grid[1] < rd->t_grid[0]) ? -1.0 : 1.0;
+    int64_t fe = 0, row = 0;
+    // f(s, y) for every segment; `ti` is the fp32 stage time in the (possibly negated) integration variable
+    auto F = [&](float ti, float* const* yin, float* const* kout) {
+        drift(yin[0], (float)(sign * (double)ti), kout[0], aux.dl ? aux.d1 : nullptr); ++fe;
+        if (aux.dl) HIP_CHECK(launch_scale(kout[1], aux.d1, (float)(-sign) * aux.div_scale, (long long)ndl, st));
+        if (sign < 0) HIP_CHECK(launch_scale(kout[0], kout[0], -1.0f, (long long)n, st));
+    };
+    auto save_from = [&](float* const* src) {
+        if (aux.dl) {
+            HIP_CHECK(launch_scale(aux.scaled, src[1], aux.out_scale, (long long)ndl, st));
+            HIP_CHECK(hipMemcpyAsync(aux.out + (size_t)row * ndl, aux.scaled, ndl * sizeof(float), out_kind, st));
+        }
+        HIP_CHECK(hipMemcpyAsync(out_path + (size_t)(row++) * n, src[0], n * sizeof(float), out_kind, st));
+    };
+    auto wants_row = [&](int i) { return rd->save_every > 0 ? (i % rd->save_every == 0 || i == N - 1) : i == N - 1; };
+    auto comb = [&](int s2, int nk, const double* c, double scale) {
+        RkComb r{};
+        r.nk = nk;
+        for (int j = 0; j < nk; ++j) { r.k[j] = k[s2][j]; r.c[j] = (float)c[j] * (float)scale; }       // beta_ij * dt in fp32
+        return r;
+    };
+    double* red = h->rk_red.p;
+    auto fetch = [&]() { double v = 0; HIP_CHECK(hipMemcpyAsync(&v, red + RED_PARTIALS, sizeof(double), hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st)); return v; };
+    const float rtol = rd->rtol, atol = rd->atol;
+    if (wants_row(0)) save_from(y);
+
+    if (rd->scheme == TI_SCHEME_MIDPOINT || rd->scheme == TI_SCHEME_RK4) {
+        // FixedGridODESolver with step_size = None: one step per grid interval (solvers.py; fixed_grid.py Midpoint / RK4)
+        for (int i = 0; i + 1 < N; ++i) {
+            const float t0 = (float)(sign * rd->t_grid[i]), t1 = (float)(sign * rd->t_grid[i + 1]), dt = t1 - t0;
+            F(t0, y, KP(0));
+            if (rd->scheme == TI_SCHEME_MIDPOINT) {
+                const double half[1] = {0.5};
+                for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_rk_combo(ytmp[s2], y[s2], comb(s2, 1, half, dt), (long long)sn[s2], st));
+                F(t0 + 0.5f * dt, ytmp, KP(1));
+                const double one[2] = {0., 1.};
+                for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_rk_combo(y[s2], y[s2], comb(s2, 2, one, dt), (long long)sn[s2], st));
+            } else {                        // rk4_alt_step_func: the 3/8 rule
+                const double c2[1] = {1. / 3}, c3[2] = {-1. / 3, 1.}, c4[3] = {1., -1., 1.}, cs[4] = {0.125, 0.375, 0.375, 0.125};
+                for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_rk_combo(ytmp[s2], y[s2], comb(s2, 1, c2, dt), (long long)sn[s2], st));
+                F(t0 + dt * (1.0f / 3.0f), ytmp, KP(1));
+                for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_rk_combo(ytmp[s2], y[s2], comb(s2, 2, c3, dt), (long long)sn[s2], st));
+                F(t0 + dt * (2.0f / 3.0f), ytmp, KP(2));
+                for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_rk_combo(ytmp[s2], y[s2], comb(s2, 3, c4, dt), (long long)sn[s2], st));
+                F(t1, ytmp, KP(3));
+                for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_rk_combo(y[s2], y[s2], comb(s2, 4, cs, dt), (long long)sn[s2], st));
+            }
+            if (wants_row(i + 1)) save_from(y);
+        }
+    } else {
+        // ---- dopri5: RKAdaptiveStepsizeODESolver (rk_common.py) ----
+        auto norm_of = [&](auto&& launch_one) {        // mixed norm: max over segments of the rms (misc.py _mixed_norm / _rms_norm)
+            double best = 0.0;
+            for (int s2 = 0; s2 < nseg; ++s2) {
+                launch_one(s2);
+                best = std::max(best, std::sqrt(fetch() / (double)sn[s2]));
+            }
+            return best;
+        };
+        const double t_first = sign * (double)rd->t_grid[0];
+        F((float)t_first, y, KP(0));
+        // _select_initial_step(func, t0, y0, order - 1 = 4, rtol, atol, norm, f0)
+        const double d0 = norm_of([&](int s2) { HIP_CHECK(launch_scaled_sumsq(red + RED_PARTIALS, red, y[s2], nullptr, y[s2], rtol, atol, (long long)sn[s2], st)); });
+        const double d1 = norm_of([&](int s2) { HIP_CHECK(launch_scaled_sumsq(red + RED_PARTIALS, red, k[s2][0], nullptr, y[s2], rtol, atol, (long long)sn[s2], st)); });
+        const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        {
+            const double one[1] = {1.};
+            for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_rk_combo(ytmp[s2], y[s2], comb(s2, 1, one, h0), (long long)sn[s2], st));
+        }
+        F((float)(t_first + h0), ytmp, KP(1));
+        const double d2 = norm_of([&](int s2) { HIP_CHECK(launch_scaled_sumsq(red + RED_PARTIALS, red, k[s2][1], k[s2][0], y[s2], rtol, atol, (long long)sn[s2], st)); }) / h0;
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 1.0 / 5.0);
+        double dt = std::min(100.0 * h0, h1);
+        double t0 = t_first, t1 = t_first;            // interpolation interval of the last accepted step
+        long long attempts = 0;
+        for (int i = 1; i < N; ++i) {
+            const double next_t = sign * (double)rd->t_grid[i];
+            while (next_t > t1) {
+                if (++attempts > 10000000LL) return fail(TI_E_NAN, "dopri5: more than 1e7 step attempts");
+                const double ts = t1, te = ts + dt;
+                if (!(te > ts)) return fail(TI_E_NAN, "dopri5: step size underflow (dt = " + std::to_string(dt) + ")");
+                const float tsf = (float)ts, dtf = (float)dt, tef = (float)te;
+                for (int sidx = 0; sidx < 6; ++sidx) {                       // _runge_kutta_step
+                    const float ti = dp5::alpha[sidx] == 1.0 ? std::nextafterf(tef, tef - 1.0f) : tsf + (float)dp5::alpha[sidx] * dtf;
+                    float* const* dst = sidx == 5 ? ynew : ytmp;             // c_sol == beta[5]: the last stage input IS y1
+                    for (int s2 = 0; s2 < nseg; ++s2)
+                        HIP_CHECK(launch_rk_combo(dst[s2], y[s2], comb(s2, sidx + 1, dp5::beta[sidx], dtf), (long long)sn[s2], st));
+                    F(ti, dst, KP(sidx + 1));
+                }
+                const double ratio = norm_of([&](int s2) {                  // _compute_error_ratio
+                    HIP_CHECK(launch_rk_ratio_sumsq(red + RED_PARTIALS, red, y[s2], ynew[s2], comb(s2, 7, dp5::c_error, dtf), rtol, atol, (long long)sn[s2], st));
+                });
+                if (!(ratio == ratio)) return fail(TI_E_NAN, "dopri5: non-finite error estimate");
+                if (ratio <= 1.0) {                                          // accept: dense output, FSAL
+                    for (int s2 = 0; s2 < nseg; ++s2) {
+                        HIP_CHECK(launch_interp_fit(coef[s2], y[s2], ynew[s2], k[s2][0], k[s2][6], comb(s2, 7, dp5::c_mid, dtf), dtf, (long long)sn[s2], st));
+                        HIP_CHECK(hipMemcpyAsync(y[s2], ynew[s2], sn[s2] * sizeof(float), hipMemcpyDeviceToDevice, st));
+                        std::swap(k[s2][0], k[s2][6]);
+                    }
+                    t0 = ts; t1 = te;
+                }
+                // _optimal_step_size(dt, ratio, safety 0.9, ifactor 10, dfactor 0.2, order 5)
+                if (ratio == 0.0) dt *= 10.0;
+                else dt *= std::min(10.0, std::max(0.9 / std::pow(ratio, 0.2), ratio < 1.0 ? 1.0 : 0.2));
+            }
+            if (wants_row(i)) {                                              // _interp_evaluate at the requested time
+                const float xrel = (float)((next_t - t0) / (t1 - t0));
+                for (int s2 = 0; s2 < nseg; ++s2) HIP_CHECK(launch_interp_eval(ytmp[s2], coef[s2], xrel, (long long)sn[s2], st));
+                save_from(ytmp);
+            }
+        }
+    }
+    HIP_CHECK(hipMemsetAsync(h->nanflag.p, 0, sizeof(int), st));
+    HIP_CHECK(launch_nan_check(x, (long long)n, h->nanflag.p, st));
+    int flag = 0;
+    HIP_CHECK(hipMemcpyAsync(&flag, h->nanflag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (n_fevals) *n_fevals = fe;
+    return flag ? fail(TI_E_NAN, "non-finite value in the final state") : TI_OK;
+}
+
 int check_rollout_desc(const ti_rollout_desc* rd)
 {
     if (!rd || !rd->t_grid) return fail(TI_E_ARG, "rollout desc / t_grid is NULL");
     if (rd->n_step < 1) return fail(TI_E_ARG, "n_step must be >= 1");
-    if (rd->scheme < TI_SCHEME_EULER || rd->scheme > TI_SCHEME_EM) return fail(TI_E_ARG, "unknown scheme");
+    if (rd->scheme < TI_SCHEME_EULER || rd->scheme > TI_SCHEME_RK4) return fail(TI_E_ARG, "unknown scheme");
+    if (rd->scheme == TI_SCHEME_DOPRI5 && !(rd->rtol > 0.f && rd->atol > 0.f)) return fail(TI_E_ARG, "dopri5 needs rtol > 0 and atol > 0");
+    if (rd->scheme >= TI_SCHEME_DOPRI5)
+        for (int k = 0; k + 2 < rd->n_step; ++k)
+            if ((rd->t_grid[k + 1] > rd->t_grid[k]) != (rd->t_grid[k + 2] > rd->t_grid[k + 1]) || rd->t_grid[k + 1] == rd->t_grid[k])
+                return fail(TI_E_ARG, "t_grid must be strictly monotonic");
     if (rd->mem != TI_MEM_HOST && rd->mem != TI_MEM_DEVICE) return fail(TI_E_ARG, "unknown mem kind");
     if (rd->eps < 0.f) return fail(TI_E_ARG, "eps must be >= 0");
     return TI_OK;
@@ -759,8 +932,9 @@ int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, c
         const float* cd = cond;
         if (rd->mem == TI_MEM_HOST && nc) { HIP_CHECK(hipMemcpyAsync(h->cond.p, cond, nc * sizeof(float), hipMemcpyHostToDevice, h->stream)); cd = h->cond.p; }
         const int saved_tap = h->tap; h->tap = -1;
-        const int rc = rollout_common(h, rd, h->x.p, h->b1.p, h->b2.p, h->xt.p, n, B, A * 3, A, out_path, n_fevals,
-                                      [&](const float* xs, float t, float* o, float*) { painn_drift_dev(h, xs, t, cd, B, o); });
+        auto drift = [&](const float* xs, float t, float* o, float*) { painn_drift_dev(h, xs, t, cd, B, o); };
+        const int rc = rd->scheme >= TI_SCHEME_DOPRI5 ? rollout_rk(h, rd, h->x.p, n, out_path, n_fevals, drift)
+                                                      : rollout_common(h, rd, h->x.p, h->b1.p, h->b2.p, h->xt.p, n, B, A * 3, A, out_path, n_fevals, drift);
         h->tap = saved_tap;
         return rc;
     });
@@ -842,14 +1016,15 @@ int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* rd, const float*
         DlogpAux aux;
         aux.dl = h->dl.p; aux.d1 = h->divb.p; aux.d2 = h->div2.p; aux.scaled = h->dlscaled.p; aux.out = out_dlogp;
         aux.n_dl = (size_t)B; aux.div_scale = div_scale; aux.out_scale = out_scale;
-        const int rc = rollout_common(h, rd, h->x.p, h->b1.p, h->b2.p, h->xt.p, n, B, A * 3, A, out_path, n_fevals,
-                                      [&](const float* xs, float t, float* o, float* dv) {
-                                          painn_drift_div_dev(h, xs, t, cd, B, o, dv);
-                                          if (reverse_ode) {      // (-b, +div): ode_wrapper.py:49
-                                              HIP_CHECK(launch_scale(o, o, -1.0f, (long long)n, h->stream));
-                                              HIP_CHECK(launch_scale(dv, dv, -1.0f, (long long)B, h->stream));
-                                          }
-                                      }, aux);
+        auto drift = [&](const float* xs, float t, float* o, float* dv) {
+            painn_drift_div_dev(h, xs, t, cd, B, o, dv);
+            if (reverse_ode) {      // (-b, +div): ode_wrapper.py:49
+                HIP_CHECK(launch_scale(o, o, -1.0f, (long long)n, h->stream));
+                HIP_CHECK(launch_scale(dv, dv, -1.0f, (long long)B, h->stream));
+            }
+        };
+        const int rc = rd->scheme >= TI_SCHEME_DOPRI5 ? rollout_rk(h, rd, h->x.p, n, out_path, n_fevals, drift, aux)
+                                                      : rollout_common(h, rd, h->x.p, h->b1.p, h->b2.p, h->xt.p, n, B, A * 3, A, out_path, n_fevals, drift, aux);
         h->tap = saved_tap;
         return rc;
     });
@@ -1037,8 +1212,9 @@ static int adw_rollout_impl(ti_handle* h, const ti_rollout_desc* rd, const float
         DlogpAux aux;
         DevBuf<float> scaled_tmp;                    // dlogp * 1e2 staging for the saved rows
         if (out_dlogp) { scaled_tmp.alloc(B); aux.dl = h->adl.p; aux.d1 = h->ad1.p; aux.d2 = h->ad2.p; aux.scaled = scaled_tmp.p; aux.out = out_dlogp; }
-        return rollout_common(h, rd, h->ax.p, h->ab1.p, h->ab2.p, h->axt.p, (size_t)B, B, 1, 0, out_path, n_fevals,
-                              [&](const float* xs, float t, float* o, float* dv) { adw_drift_dev(h, xs, t, U, B, o, dv); }, aux);
+        auto drift = [&](const float* xs, float t, float* o, float* dv) { adw_drift_dev(h, xs, t, U, B, o, dv); };
+        if (rd->scheme >= TI_SCHEME_DOPRI5) return rollout_rk(h, rd, h->ax.p, (size_t)B, out_path, n_fevals, drift, aux);
+        return rollout_common(h, rd, h->ax.p, h->ab1.p, h->ab2.p, h->axt.p, (size_t)B, B, 1, 0, out_path, n_fevals, drift, aux);
     });
 }
 

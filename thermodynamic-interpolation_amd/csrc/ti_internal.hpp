@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -140,6 +141,20 @@ hipError_t launch_noise(float* x, float sigma, uint64_t seed, long long traj0, i
 hipError_t launch_scale(float* y, const float* x, float a, long long n, hipStream_t st);                            // y = a*x
 hipError_t launch_selftest(float* out /*[64*16]*/, hipStream_t st);
 hipError_t launch_nan_check(const float* x, long long n, int* flag, hipStream_t st);
+
+// ---- Runge-Kutta pieces (ode_kernels.hip)
+struct RkComb { const float* k[7]; float c[7]; int nk; };     // sum_j c[j] * k[j][i], j < nk
+constexpr int RED_PARTIALS = 1024;                             // size of the `partial` scratch (doubles) of the reductions below
+hipError_t launch_rk_combo(float* y, const float* y0, const RkComb& c, long long n, hipStream_t st);               // y = y0 + comb
+// *out = sum_i (comb_i / (atol + rtol max(|y0_i|, |y1_i|)))^2, fixed summation order
+hipError_t launch_rk_ratio_sumsq(double* out, double* partial, const float* y0, const float* y1, const RkComb& c, float rtol, float atol,
+                                 long long n, hipStream_t st);
+// *out = sum_i ((a_i - b_i) / (atol + rtol |y0_i|))^2   (b may be NULL)
+hipError_t launch_scaled_sumsq(double* out, double* partial, const float* a, const float* b, const float* y0, float rtol, float atol,
+                               long long n, hipStream_t st);
+hipError_t launch_interp_fit(float* coef /*[5][n]*/, const float* y0, const float* y1, const float* f0, const float* f1, const RkComb& mid,
+                             float dt, long long n, hipStream_t st);
+hipError_t launch_interp_eval(float* out, const float* coef, float x, long long n, hipStream_t st);
 
 // ---- host-side weight packing (pack.cpp)
 // One chunk = 32 output rows [row0, row0+32) x F_in = 32*NBin input columns [col0, col0+F_in) of a row-major W[out][ld],

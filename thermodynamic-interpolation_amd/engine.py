@@ -36,7 +36,7 @@ def _time_grid_numpy(start: float, end: float, n_step: int) -> np.ndarray:
     return np.where(i < n_step // 2, lo, hi).astype(np.float32)
 
 
-def _rollout_desc(scheme, t_grid, save_every, mem, eps, seed, traj_offset, com_free_noise):
+def _rollout_desc(scheme, t_grid, save_every, mem, eps, seed, traj_offset, com_free_noise, rtol=0.0, atol=0.0):
     t_grid = np.ascontiguousarray(t_grid, np.float32)
     if t_grid.ndim != 1 or t_grid.size < 1:
         raise ValueError("t_grid must be a non-empty 1-D array")
@@ -45,7 +45,7 @@ def _rollout_desc(scheme, t_grid, save_every, mem, eps, seed, traj_offset, com_f
             raise ValueError(f"unknown scheme {scheme!r}; expected one of {sorted(_lib.SCHEMES)}")
         scheme = _lib.SCHEMES[scheme]
     rd = _lib.RolloutDesc(scheme, t_grid.size, int(save_every), mem, float(eps), int(bool(com_free_noise)), int(seed),
-                          int(traj_offset), _lib.fptr(t_grid))
+                          int(traj_offset), _lib.fptr(t_grid), float(rtol), float(atol))
     rd._keep = t_grid
     return rd
 
@@ -131,13 +131,15 @@ class PainnEngine(_Engine):
         _lib.check(_lib.lib().ti_painn_drift(self.h, xp, float(t), cp, B, op, _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
         return out
 
-    def rollout(self, x0, cond, t_grid, scheme="euler", save_every=1, eps=0.0, seed=0, traj_offset=0, com_free_noise=False, out=None):
-        """Returns (path [rows,B,A,3], n_fevals)."""
+    def rollout(self, x0, cond, t_grid, scheme="euler", save_every=1, eps=0.0, seed=0, traj_offset=0, com_free_noise=False, out=None,
+                rtol=1e-4, atol=1e-4):
+        """Returns (path [rows,B,A,3], n_fevals).  scheme: 'euler' | 'heun' | 'em' | 'midpoint' | 'rk4' on the grid, or 'dopri5'
+        (adaptive, tolerances rtol / atol; the grid then only selects the output times)."""
         B = int(x0.shape[0])
         if tuple(x0.shape[1:]) != (self.A, 3):
             raise ValueError(f"x0 must be [B,{self.A},3]")
         xp, cp, dev, keep = self._bufs(x0, cond)
-        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, eps, seed, traj_offset, com_free_noise)
+        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, eps, seed, traj_offset, com_free_noise, rtol, atol)
         rows = int(_lib.lib().ti_rollout_rows(rd.n_step, rd.save_every))
         out = _alloc_like(x0 if dev else None, (rows, B, self.A, 3)) if out is None else out
         op, _, odev = _lib.as_ptr(out)
@@ -173,14 +175,15 @@ class PainnEngine(_Engine):
                                                  _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
         return out, div
 
-    def rollout_dlogp(self, x0, cond, t_grid, scheme="euler", save_every=1, div_scale=1.0, out_scale=1.0, reverse_ode=False):
+    def rollout_dlogp(self, x0, cond, t_grid, scheme="euler", save_every=1, div_scale=1.0, out_scale=1.0, reverse_ode=False,
+                      rtol=1e-4, atol=1e-4):
         """Two-state rollout (x, dlogp): returns (path [rows,B,A,3], dlogp [rows,B], n_fevals).  d(dlogp)/dt = -div_scale * div
         (reverse_ode: (-b, +div_scale * div) on the descending grid the caller passes), dlogp is written * out_scale."""
         B = int(x0.shape[0])
         if tuple(x0.shape[1:]) != (self.A, 3):
             raise ValueError(f"x0 must be [B,{self.A},3]")
         xp, cp, dev, keep = self._bufs(x0, cond)
-        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, 0.0, 0, 0, False)
+        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, 0.0, 0, 0, False, rtol, atol)
         rows = int(_lib.lib().ti_rollout_rows(rd.n_step, rd.save_every))
         out, dl = _alloc_like(x0 if dev else None, (rows, B, self.A, 3)), _alloc_like(x0 if dev else None, (rows, B))
         nfe = C.c_int64(0)
@@ -238,12 +241,12 @@ class AdwEngine(_Engine):
         return out, div
 
     def rollout(self, x0, beta0, beta1, t_grid, scheme="euler", save_every=1, eps=0.0, seed=0, traj_offset=0, out=None,
-                return_dlogp=False):
+                return_dlogp=False, rtol=1e-4, atol=1e-4):
         """(path [rows,B], n_fevals), or (path, dlogp [rows,B] (already * 1e2 like the reference), n_fevals)."""
         B = int(x0.shape[0])
         dev = self._same_space(x0, beta0, beta1)
         (xp, xk, _), (b0p, b0k, _), (b1p, b1k, _) = _lib.as_ptr(x0), _lib.as_ptr(beta0), _lib.as_ptr(beta1)
-        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, eps, seed, traj_offset, False)
+        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, eps, seed, traj_offset, False, rtol, atol)
         rows = int(_lib.lib().ti_rollout_rows(rd.n_step, rd.save_every))
         out = _alloc_like(x0 if dev else None, (rows, B)) if out is None else out
         op, _, _ = _lib.as_ptr(out)

@@ -3,22 +3,22 @@ from __future__ import annotations
 
 import numpy as np
 
-FIXED_STEP = ("euler", "heun", "em")
-# torchdiffeq method names the reference passes ('dopri5' in every shipped config).  The adaptive solvers live
-# in a third-party package that is not part of the reference checkout; they are not reproduced (parity unpinned there).
-ADAPTIVE = ("dopri5", "dopri8", "bosh3", "fehlberg2", "adaptive_heun", "rk4", "midpoint", "explicit_adams", "implicit_adams",
-            "fixed_adams", "scipy_solver")
+# Solver names: torchdiffeq's 'dopri5' (the reference default), 'euler', 'midpoint', 'rk4' restate torchdiffeq
+# 0.2.5 (ti_env.yml:14; third-party, absent from the reference checkout -- parity unpinned against the library itself);
+# 'heun' and 'em' are build-defined (include/ti_hip.h).
+SUPPORTED = ("dopri5", "euler", "midpoint", "rk4", "heun", "em")
+NOT_BUILT = ("dopri8", "bosh3", "fehlberg2", "adaptive_heun", "heun2", "heun3", "explicit_adams", "implicit_adams", "fixed_adams",
+             "scipy_solver")
 
 
 def check_method(method: str) -> str:
-    if method in FIXED_STEP:
+    if method in SUPPORTED:
         return method
-    if method in ADAPTIVE:
+    if method in NOT_BUILT:
         raise NotImplementedError(
-            f"method={method!r} is a torchdiffeq solver (third-party, absent from the reference checkout); this build provides the "
-            f"fixed-step schemes {FIXED_STEP} on the same torch.linspace(start, end, n_step) grid.  'euler' equals torchdiffeq's "
-            "method='euler' on that grid; use method='heun' for second order.")
-    raise ValueError(f"unknown method {method!r}; expected one of {FIXED_STEP}")
+            f"method={method!r} is a torchdiffeq solver that is not built here (torchdiffeq is third-party and absent from the "
+            f"reference checkout); available: {SUPPORTED}.")
+    raise ValueError(f"unknown method {method!r}; expected one of {SUPPORTED}")
 
 
 def is_torch(x) -> bool:

@@ -123,7 +123,8 @@ class PaiNNShell:
 
 
 class MoleculeIntegratorBase:
-    """rollout(batch) with the reference's constructor; fixed-step schemes only (see _common.check_method).
+    """rollout(batch) with the reference's constructor.  method: 'dopri5' (the reference default; adaptive with rtol / atol, the
+    grid linspace(start, end, n_step) selects the output times) or a scheme on that grid (see _common.check_method).
 
     return_dlogp=True integrates the second state of the reference ODEWrapper with the same scheme: d(dlogp)/dt = -DIV_SCALE *
     div b (exact divergence, 3A forward-mode passes per molecule on the GPU), returned * SCALE_DLOGP as [n_saved, B].  With
@@ -153,10 +154,10 @@ class MoleculeIntegratorBase:
                 grid = _engine.time_grid(self.end, self.start, self.n_step)
             path, dl, nfe = eng.rollout_dlogp(x0, self.b.cond_of(batch, B, A), grid, scheme="euler" if self.method == "em" else self.method,
                                               save_every=self.save_every, div_scale=self.DIV_SCALE, out_scale=self.SCALE_DLOGP,
-                                              reverse_ode=self.reverse_ode)
+                                              reverse_ode=self.reverse_ode, rtol=self.rtol, atol=self.atol)
             return C.like(path.reshape(path.shape[0], B * A, 3), batch.x0), C.like(dl, batch.x0), nfe
         path, nfe = eng.rollout(x0, self.b.cond_of(batch, B, A), grid, scheme=self.method, save_every=self.save_every, eps=self.eps,
-                                seed=self.seed, traj_offset=traj_offset, com_free_noise=self.com_free_noise)
+                                seed=self.seed, traj_offset=traj_offset, com_free_noise=self.com_free_noise, rtol=self.rtol, atol=self.atol)
         xts = C.like(path.reshape(path.shape[0], B * A, 3), batch.x0)
         dlogp = C.like(np.zeros(B, np.float32) * self.SCALE_DLOGP, batch.x0)      # reference: zeros(batch_size) (* 1e2 in ambient)
         return xts, dlogp, nfe

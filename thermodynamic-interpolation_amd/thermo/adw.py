@@ -119,7 +119,8 @@ class ODEWrapper:
 class StandardIntegrator:
     """rollout(x0s, beta0s, beta1s) -> (x [n_saved, B, 1], dlogp)   -- reference: (x [n_step, B, 1], dlogp * 1e2).
 
-    ``method``: 'euler' | 'heun' | 'em' on the grid torch.linspace(start, end, n_step) (n_step - 1 steps).  Extra keyword
+    ``method``: 'dopri5' (adaptive, rtol / atol; the grid selects the output times) or 'euler' | 'midpoint' | 'rk4' | 'heun' | 'em'
+    on the grid torch.linspace(start, end, n_step) (n_step - 1 steps).  Extra keyword
     arguments are build-defined: ``eps``/``seed`` (EM noise), ``save_every`` (1 keeps every grid point like the reference;
     0 keeps the end state only).  With return_dlogp=True the second ODE state d(dlogp)/dt = -div * 1e-2 is integrated with the
     same scheme and returned * 1e2 as [n_saved, B, 1], like the reference (integrators.py:38-68).  With return_dlogp=False the
@@ -144,7 +145,7 @@ class StandardIntegrator:
         grid = _engine.time_grid(self.start, self.end, self.n_step)
         res = self.ode_wrapper.b.engine().rollout(np.ascontiguousarray(x0[:, 0]), b0, b1, grid, scheme=self.method,
                                                   save_every=self.save_every, eps=self.eps, seed=self.seed, traj_offset=traj_offset,
-                                                  return_dlogp=bool(self.return_dlogp))
+                                                  return_dlogp=bool(self.return_dlogp), rtol=self.rtol, atol=self.atol)
         self.n_fevals = res[-1]
         dlogp = C.like(res[1][:, :, None], x0s) if self.return_dlogp else None
         return C.like(res[0][:, :, None], x0s), dlogp
