@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert sorted(ti._lib.ABI_SYMBOLS) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ti_version() == 1
+    assert lib.ti_version() == 2          # TI_ABI_VERSION: ti_rollout_desc gained rtol / atol
 
 
 def test_rollout_rows_matches_oracle_definition(lib):
