@@ -5,8 +5,8 @@
   sample_adw     <- /root/reference/adw/sample.py:14-81              initial_samples/samples/dlogps _epoch_{k}.npy under beta_{b0}_to_{b1}/
   load_config    <- /root/reference/mdqm9/thermo/utils.py:31-47      JSON file -> argparse.Namespace (keys become --options)
 
-Differences, on purpose: the fixed-step `method` comes from ``config.method`` (default 'heun'; the reference hard-codes the
-third-party 'dopri5'); files are written once per call instead of re-saving the growing concatenation after every batch
+Differences, on purpose: `method` comes from ``config.method`` (default 'dopri5' like the reference's hard-coded solver; any
+name of thermo._common.SUPPORTED works); files are written once per call instead of re-saving the growing concatenation after every batch
 (O(n_batches^2) I/O in the reference); datasets are the numpy ones of ``data.py``.
 """
 from __future__ import annotations
@@ -39,7 +39,7 @@ def _regroup(sample, batch_idx):
 
 def sample_ambient(config, b, dataset):
     os.makedirs(config.data_save_path, exist_ok=True)
-    integrator = _amb.MoleculeIntegrator(b=b, method=getattr(config, "method", "heun"), rtol=config.rtol, atol=config.atol,
+    integrator = _amb.MoleculeIntegrator(b=b, method=getattr(config, "method", "dopri5"), rtol=config.rtol, atol=config.atol,
                                          n_step=config.n_steps, return_dlogp=bool(config.return_dlogp), reverse_ode=False,
                                          save_every=getattr(config, "save_every", 1))
     latent_noises, latent_dlogps, samples, dlogps, n_fevals = [], [], [], [], 0
@@ -63,7 +63,7 @@ def sample_ambient(config, b, dataset):
 
 def sample_latent(config, b, dataset):
     os.makedirs(config.data_save_path, exist_ok=True)
-    integrator = _lat.MoleculeIntegrator(b=b, method=getattr(config, "method", "heun"), rtol=config.rtol, atol=config.atol,
+    integrator = _lat.MoleculeIntegrator(b=b, method=getattr(config, "method", "dopri5"), rtol=config.rtol, atol=config.atol,
                                          n_step=config.n_steps, return_dlogp=bool(config.return_dlogp), reverse_ode=False,
                                          save_every=getattr(config, "save_every", 1))
     samples, dlogps = [], []
