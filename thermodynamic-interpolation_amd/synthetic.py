@@ -105,3 +105,27 @@ def latent_cond(B: int, A: int, T: float = 800.0) -> np.ndarray:
 
 def adw_x0(B: int, seed: int = 0) -> np.ndarray:
     return np.random.RandomState(seed).standard_normal(B).astype(np.float32)
+
+
+def adw_potential(x):
+    """The asymmetric double well of the adw experiments, U(x) = 4 (x^2 - 1)^2 + x / 2."""
+    x = np.asarray(x, np.float64)
+    return 4.0 * (x * x - 1.0) ** 2 + 0.5 * x
+
+
+def adw_boltzmann(B: int, beta: float, seed: int = 0, lo: float = -3.0, hi: float = 3.0, n_grid: int = 60001) -> np.ndarray:
+    """B independent samples of exp(-beta U) by inverse-CDF on a fine grid (stands in for the reference's samples.csv, which is
+    not available offline)."""
+    grid = np.linspace(lo, hi, n_grid)
+    pdf = np.exp(-beta * (adw_potential(grid) - adw_potential(grid).min()))
+    cdf = np.concatenate([[0.0], np.cumsum(0.5 * (pdf[1:] + pdf[:-1]))])
+    cdf /= cdf[-1]
+    return np.interp(np.random.RandomState(seed).random_sample(B), cdf, grid)
+
+
+def adw_expectations(beta: float, lo: float = -3.0, hi: float = 3.0, n_grid: int = 60001) -> dict:
+    """Quadrature values of <x>, <x^2>, P(x < 0) under exp(-beta U)."""
+    grid = np.linspace(lo, hi, n_grid)
+    w = np.exp(-beta * (adw_potential(grid) - adw_potential(grid).min()))
+    w /= w.sum()
+    return {"mean": float((w * grid).sum()), "second": float((w * grid * grid).sum()), "left": float(w[grid < 0].sum())}
