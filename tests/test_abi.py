@@ -67,3 +67,10 @@ def test_create_argument_validation(lib):
     assert not h and "n_atoms" in lib.ti_last_error().decode()
     assert lib.ti_painn_drift(None, None, C.c_float(0), None, 1, None, 0) == ti._lib.TI_E_ARG
     assert lib.ti_adw_rollout(None, None, None, None, None, 1, None, None) == ti._lib.TI_E_ARG
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check: build() compiles (or finds up to date) every HIP object, loads the library, checks the
+    ABI version and builds the oracle."""
+    import __graft_entry__ as entry
+    entry.build()
