@@ -468,6 +468,61 @@ __device__ __forceinline__ void ln_silu_dual(Act<NBK>& a, Act<NBK>& da, const fl
     }
 }
 
+// LayerNorm + SiLU that also returns what a tangent through it needs:  n = (h - mean) rstd  and  kk = rstd g silu'(y),
+// so that later  da = kk ((dh - mean(dh)) - n mean(n (dh - mean(dh))))   (ln_tangent below).  `a` matches ln_silu bit for bit.
+template <int NBK>
+__device__ __forceinline__ void ln_silu_stats(Act<NBK>& a, Act<NBK>& n_out, Act<NBK>& k_out, const float* gamma, const float* beta, int q)
+{
+    constexpr float invF = 1.0f / (16.0f * NBK);
+    float sum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) sum += (a.b[nb].x + a.b[nb].y) + (a.b[nb].z + a.b[nb].w);
+    const float mean = xquarters(sum) * invF;
+    float var = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = a.b[nb][r] - mean;
+            var = fmaf(d, d, var);
+        }
+    const float rstd = 1.0f / sqrtf(xquarters(var) * invF + 1e-5f);
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const f32x4 gm = load_block(gamma, nb, q), bt = load_block(beta, nb, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float n = (a.b[nb][r] - mean) * rstd;
+            const float y = fmaf(n, gm[r], bt[r]);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+            a.b[nb][r] = y * sg;
+            n_out.b[nb][r] = n;
+            k_out.b[nb][r] = (rstd * gm[r]) * (sg * fmaf(y, 1.0f - sg, 1.0f));
+        }
+    }
+}
+
+// tangent through LayerNorm + SiLU from the stored (n, kk) of the primal row; in place on the tangent pre-activation
+template <int NBK>
+__device__ __forceinline__ void ln_tangent(Act<NBK>& da, const Act<NBK>& n, const Act<NBK>& kk)
+{
+    constexpr float invF = 1.0f / (16.0f * NBK);
+    float dsum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) dsum += (da.b[nb].x + da.b[nb].y) + (da.b[nb].z + da.b[nb].w);
+    const float dmean = xquarters(dsum) * invF;
+    float pr = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr = fmaf(n.b[nb][r], da.b[nb][r] - dmean, pr);
+    const float proj = xquarters(pr) * invF;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) da.b[nb][r] = kk.b[nb][r] * ((da.b[nb][r] - dmean) - n.b[nb][r] * proj);
+}
+
 // posenc_set and its derivative along dx_over_len:  d cos(a) = -sin(a) da,  d sin(a) = cos(a) da,  da = (dx_over_len k) pi
 template <int NBK>
 __device__ __forceinline__ void posenc_dual(Act<NBK>& a, Act<NBK>& da, float x_over_len, float dx_over_len, int q)

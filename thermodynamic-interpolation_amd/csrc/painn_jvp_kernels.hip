@@ -16,9 +16,10 @@
 //
 // The filter branch w(enc(|r|)) depends on x only through the edge length, so its tangent is rank one:
 //   d w_o[edge][dir] = d|r|[edge][dir] * Q[edge],  Q = (d w_o / d |r|).
-// painn_jvp_filter_kernel evaluates w_o and Q ONCE per primal edge and layer (a dual pass seeded with d|r| = 1) and parks
-// them in HBM in the register layout of the flipped output stage; the per-direction edge kernel then runs only the phi
-// branch -- half the matrix work of differentiating both branches per direction.
+// painn_jvp_filter_kernel (the "primal pass") evaluates w_o and Q ONCE per primal edge and layer (a dual pass seeded with
+// d|r| = 1), together with the phi branch's forward values and LayerNorm statistics, and parks them in HBM in the register
+// layouts the per-direction edge kernel consumes; that kernel is left with the TANGENT of the phi branch only -- a quarter
+// of the matrix work of differentiating both branches per direction, and no transcendental per (edge, direction).
 //
 // Tangent rules restated from the forward pass (painn_kernels.hip; reference lines there):
 //   geometry  r = x_s - x_d, d = |r|, dir = r / (1 + d):   dd = r.dr / d,  ddir = dr / (1 + d) - r dd / (1 + d)^2
@@ -50,10 +51,14 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 
 }  // namespace
 
-// ================================================================================================== filter pass
-// w_o + bias and Q = d w_o / d |r| of every primal edge of this layer, in the flipped-accumulator layout:
-//   wq[((((pg * nblk + blk) * 5 + c) * NB + nbo) * 4 + k) * 64 + lane]   k: 0/1 = w_o features 32 nbo + {0,16} + (lane & 15),
-//   2/3 = Q of the same; float4 = the block's rows 4 (lane >> 4) .. + 3.   One wave per primal group.
+// ================================================================================================== primal pass
+// Everything the per-direction edge kernel needs from the forward pass of this layer's message block, ONCE per primal edge:
+//   wq[((((pg * nblk + blk) * 5 + c) * NB + nbo) * 6 + k) * 64 + lane]  (float4 = the block's rows 4 (lane >> 4) .. + 3)
+//        k = 0/1: phi_o + bias (features 32 nbo + {0,16} + (lane & 15)),  2/3: w_o + bias,  4/5: Q = d w_o / d|r|
+//   st[(((pg * nblk + blk) * 4 + which) * NBK + nb) * 64 + lane]        which = n, kk of phi's two LayerNorms (ln_silu_stats),
+//        float4 = features 16 nb + 4 (lane >> 4) .. + 3 of row (lane & 15)
+// The filter branch runs as a (value, tangent) pair seeded with d|r| = 1 (-> Q), the phi branch as the plain forward pass.
+// Reads the primal edge stream of painn_edge_kernel (same chunk order); one wave per primal group.
 template <int NBK, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void painn_jvp_filter_kernel(const JvpFilterParams p)
 {
@@ -78,10 +83,12 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_filter_kernel(const JvpFilte
         long long pm = gi * p.G + row_mol(meta);
         pm = pm < p.B ? pm : p.B - 1;
         const long long nsrc = pm * p.A + row_src(meta), ndst = pm * p.A + row_dst(meta);
+        const size_t prow0 = ((size_t)gi * p.nblk + blk) * 16;
         const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
         const float ry = p.x[nsrc * 3 + 1] - p.x[ndst * 3 + 1];
         const float rz = p.x[nsrc * 3 + 2] - p.x[ndst * 3 + 2];
         const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+        // ---- filter branch, (value, d/d|r|) pair
         OP g2, tg2;
         {
             A16 t1, u1;
@@ -119,33 +126,87 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_filter_kernel(const JvpFilte
             r16::ln_silu_dual(t1, u1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
             g2.set(t1); tg2.set(u1);
         }
-        f32x4* wq = reinterpret_cast<f32x4*>(p.wq) + ((size_t)(gi * p.nblk + blk) * 5 * NB) * 4 * 64 + lane;
+        // ---- phi branch forward, LayerNorm statistics parked for the tangent passes
+        OP h2;
+        {
+            f32x4* stp = reinterpret_cast<f32x4*>(p.st) + ((size_t)(gi * p.nblk + blk) * 4 * NBK) * 64 + lane;
+            auto park = [&](int which, const A16& v) {
+                if (group_ok) {
+#pragma unroll
+                    for (int nb = 0; nb < NBK; ++nb) stp[(size_t)(which * NBK + nb) * 64] = v.b[nb];
+                }
+            };
+            A16 t1;
+            {
+                OP ein;
+                if (first) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
+                else       r16::load_set(t1, p.e + (prow0 + j) * F, q);
+                ein.set(t1);
+                const float* prow = p.P + (size_t)nsrc * F;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
+                    r16::gemm_bt(a0, a1, ein, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
+                    pipe.release();
+                }
+            }
+            {
+                A16 nn, kk;
+                r16::ln_silu_stats(t1, nn, kk, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
+                park(0, nn); park(1, kk);
+            }
+            {
+                OP h1;
+                h1.set(t1);
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const f32x4* wl = pipe.acquire();
+                    f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
+                    r16::gemm_bt(a0, a1, h1, wl, lane);
+                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
+                    pipe.release();
+                }
+            }
+            {
+                A16 nn, kk;
+                r16::ln_silu_stats(t1, nn, kk, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
+                park(2, nn); park(3, kk);
+            }
+            h2.set(t1);
+        }
+        f32x4* wq = reinterpret_cast<f32x4*>(p.wq) + ((size_t)(gi * p.nblk + blk) * 5 * NB) * 6 * 64 + lane;
         auto put = [&](int c, int nbo) {
-            f32x4 b0 = Z4, b1 = Z4, tb0 = Z4, tb1 = Z4;
-            const f32x4* wl = pipe.acquire();
-            r16::gemm_fl2(b0, b1, tb0, tb1, g2, tg2, wl, lane);
+            f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4, tb0 = Z4, tb1 = Z4;
+            const f32x4* wl0 = pipe.acquire();
+            r16::gemm_fl(a0, a1, h2, wl0, lane);
             pipe.release();
+            const f32x4* wl1 = pipe.acquire();
+            r16::gemm_fl2(b0, b1, tb0, tb1, g2, tg2, wl1, lane);
+            pipe.release();
+            const float* bp = vec + (EV::P_B2 + c) * F + 32 * nbo + j;
             const float* bw = vec + (EV::W_B2 + c) * F + 32 * nbo + j;
             if (group_ok) {
-                f32x4* o = wq + (size_t)(c * NB + nbo) * 4 * 64;
-                o[0] = b0 + bw[0]; o[64] = b1 + bw[16]; o[128] = tb0; o[192] = tb1;
+                f32x4* o = wq + (size_t)(c * NB + nbo) * 6 * 64;
+                o[0] = a0 + bp[0]; o[64] = a1 + bp[16]; o[128] = b0 + bw[0]; o[192] = b1 + bw[16]; o[256] = tb0; o[320] = tb1;
             }
         };
 #pragma unroll 1
-        for (int nbo = 0; nbo < NB; ++nbo) {          // consumption order of the edge kernels: ds, de, sed, gates, cross gates
+        for (int nbo = 0; nbo < NB; ++nbo) {          // consumption order of painn_edge_kernel: ds, de, sed, gates, cross gates
             put(2, nbo);
             if (!last) put(3, nbo);
             put(1, nbo);
             if (!first) { put(0, nbo); put(4, nbo); }
         }
-        if (p.pad) { (void)pipe.acquire(); pipe.release(); }      // odd chunk count: swallow the pad chunk, stay in phase with the superchunk ring
     }
 }
 
 // ================================================================================================== tangent edge kernel
-// One wave per virtual group; only the phi branch is differentiated here (see the header).
+// One wave per virtual group.  Per (edge, direction) row only TANGENT products remain: the phi branch's hidden layers and
+// output chunks applied to the tangent of [s[src] | e]; every primal quantity comes from the primal pass above.
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgeParams p)
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel(const JvpEdgeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -172,7 +233,6 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
         long long pm = pg * p.G + row_mol(meta);
         pm = pm < p.B ? pm : p.B - 1;
         const long long nsrc = pm * p.A + row_src(meta), ndst = pm * p.A + row_dst(meta);
-        const size_t prow0 = ((size_t)pg * p.nblk + blk) * 16;                       // primal rows of this block
         const size_t trow0 = ((size_t)gi * p.nblk + blk) * 16;                       // tangent rows of this block
         {
             const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
@@ -196,55 +256,55 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
                 *reinterpret_cast<f32x4*>(scratch + j * 8 + 4) = f32x4{tx / den - rx * k, ty / den - ry * k, tz / den - rz * k, 0.f};
             }
         }
-        // ---- phi([s[src] | e]) hidden layers, value and tangent (first layer: s and e do not depend on x, tangent = 0)
-        OP h2, th2;
-        {
-            A16 t1, u1;
-            {
-                OP ein, tein;
-                if (first) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
-                else       r16::load_set(t1, p.e + (prow0 + j) * F, q);
-                ein.set(t1);
-                if (first) {
+        // ---- tangent of phi's hidden layers (first layer: s and e do not depend on x yet, the whole tangent is zero)
+        OP th2;
+        if (!first) {
+            const f32x4* stp = reinterpret_cast<const f32x4*>(p.st) + ((size_t)(pg * p.nblk + blk) * 4 * NBK) * 64 + lane;
+            auto stat = [&](int which, A16& v) {
 #pragma unroll
-                    for (int nb = 0; nb < NBK; ++nb) u1.b[nb] = Z4;
-                } else r16::load_set(u1, p.te + (trow0 + j) * F, q);
+                for (int nb = 0; nb < NBK; ++nb) v.b[nb] = stp[(size_t)(which * NBK + nb) * 64];
+            };
+            A16 u1;
+            {
+                OP tein;
+                r16::load_set(u1, p.te + (trow0 + j) * F, q);
                 tein.set(u1);
-                const float* prow = p.P + (size_t)nsrc * F;
                 const float* tprow = p.tP + (size_t)((gi * p.G + row_mol(meta)) * p.A + row_src(meta)) * F;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const f32x4* wl = pipe.acquire();
-                    f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
-                    f32x4 b0 = Z4, b1 = Z4;
-                    if (first) r16::gemm_bt(a0, a1, ein, wl, lane);
-                    else {
-                        b0 = r16::load_block(tprow, 2 * c, q); b1 = r16::load_block(tprow, 2 * c + 1, q);
-                        r16::gemm_bt2(a0, a1, b0, b1, ein, tein, wl, lane);
-                    }
-                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    f32x4 b0 = r16::load_block(tprow, 2 * c, q), b1 = r16::load_block(tprow, 2 * c + 1, q);
+                    r16::gemm_bt(b0, b1, tein, wl, lane);
+                    u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
                     pipe.release();
                 }
             }
-            if (first) r16::ln_silu(t1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
-            else       r16::ln_silu_dual(t1, u1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
             {
-                OP h1, th1;
-                h1.set(t1); th1.set(u1);
+                A16 nn, kk;
+                stat(0, nn); stat(1, kk);
+                r16::ln_tangent(u1, nn, kk);
+            }
+            {
+                OP th1;
+                th1.set(u1);
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const f32x4* wl = pipe.acquire();
-                    f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
                     f32x4 b0 = Z4, b1 = Z4;
-                    if (first) r16::gemm_bt(a0, a1, h1, wl, lane);
-                    else       r16::gemm_bt2(a0, a1, b0, b1, h1, th1, wl, lane);
-                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1; u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
+                    r16::gemm_bt(b0, b1, th1, wl, lane);
+                    u1.b[2 * c] = b0; u1.b[2 * c + 1] = b1;
                     pipe.release();
                 }
             }
-            if (first) r16::ln_silu(t1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
-            else       r16::ln_silu_dual(t1, u1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
-            h2.set(t1); th2.set(u1);
+            {
+                A16 nn, kk;
+                stat(2, nn); stat(3, kk);
+                r16::ln_tangent(u1, nn, kk);
+            }
+            th2.set(u1);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2 * NB; ++c) { (void)pipe.acquire(); pipe.release(); }      // keep the stream in phase
         }
         // ---- output layer, flipped (features on lanes, the block's rows 4q + r in registers); see painn_edge_kernel
         uint32_t mi[4];
@@ -266,18 +326,15 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_edge_kernel(const JvpEdgePar
             tdir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 8 + 4);
             dd[r] = dir[r][3];
         }
-        const f32x4* wq = reinterpret_cast<const f32x4*>(p.wq) + ((size_t)(pg * p.nblk + blk) * 5 * NB) * 4 * 64 + lane;
+        const f32x4* wq = reinterpret_cast<const f32x4*>(p.wq) + ((size_t)(pg * p.nblk + blk) * 5 * NB) * 6 * 64 + lane;
         // value and tangent of (phi_c + b)(w_c + b) for output chunk c, 32 features as two 16-feature blocks
         auto out_pair = [&](int c, int nbo, f32x4& r0, f32x4& r1, f32x4& d0, f32x4& d1) {
-            const f32x4* g = wq + (size_t)(c * NB + nbo) * 4 * 64;
-            const f32x4 B0 = g[0], B1 = g[64], Q0 = g[128], Q1 = g[192];
-            f32x4 a0 = Z4, a1 = Z4, ta0 = Z4, ta1 = Z4;
+            const f32x4* g = wq + (size_t)(c * NB + nbo) * 6 * 64;
+            const f32x4 A0 = g[0], A1 = g[64], B0 = g[128], B1 = g[192], Q0 = g[256], Q1 = g[320];
+            f32x4 ta0 = Z4, ta1 = Z4;
             const f32x4* wl = pipe.acquire();
-            if (first) r16::gemm_fl(a0, a1, h2, wl, lane);
-            else       r16::gemm_fl2(a0, a1, ta0, ta1, h2, th2, wl, lane);
+            if (!first) r16::gemm_fl(ta0, ta1, th2, wl, lane);
             pipe.release();
-            const float* bp = vec + (EV::P_B2 + c) * F + 32 * nbo + j;
-            const f32x4 A0 = a0 + bp[0], A1 = a1 + bp[16];
             r0 = A0 * B0; r1 = A1 * B1;
             d0 = ta0 * B0 + A0 * (dd * Q0); d1 = ta1 * B1 + A1 * (dd * Q1);
         };

@@ -122,8 +122,8 @@ struct ti_handle {
     DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs, upd_vecs;
     int tap = -1; long long last_B = 0;
     // forward-mode derivative (painn_jvp_kernels.hip): tangent twins over virtual molecules, sized on first use
-    std::vector<Stream> st_jvp_update, st_jvp_w, st_jvp_phi; Stream st_jvp_readout{}; std::vector<int> jvp_w_pad, jvp_phi_pad;
-    DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, wq, divb, dl, dlscaled, div2;
+    std::vector<Stream> st_jvp_update, st_jvp_phi; Stream st_jvp_readout{}; std::vector<int> jvp_phi_pad;
+    DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, wq, phist, divb, dl, dlscaled, div2;
     long long jvp_cap = 0, last_VB = 0; int last_D = 1;
     // Runge-Kutta drivers (rollout_rk): stage derivatives, dense-output coefficients, reduction scratch
     DevBuf<float> rk_ws; DevBuf<double> rk_red;
@@ -255,11 +255,11 @@ void pack_painn(ti_handle* h, const float* wts)
         if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);                            // phase D
         pad_even(o);                                                                  // whole superchunks
         h->st_update.push_back(end_stream(o));
-        // tangent kernels (painn_jvp_kernels.hip): the filter branch and the phi branch as separate streams, same chunk order
-        for (int which = 0; which < 2; ++which) {
-            const MlpOff& m = which == 0 ? h->w[l] : h->phi[l];
+        // tangent edge kernel (painn_jvp_kernels.hip): the phi branch's chunks in the consumption order of the edge kernels
+        for (int which = 1; which < 2; ++which) {      // the phi branch alone (the primal pass reads the primal edge stream)
+            const MlpOff& m = h->phi[l];
             o = begin_stream();
-            if (which == 0) layer16(m.W0, F, F, 0); else layer16(m.W0, 2 * F, F, F);
+            layer16(m.W0, 2 * F, F, F);
             layer16(m.W1, F, F, 0);
             for (int nbo = 0; nbo < NB; ++nbo)
                 for (int c : {2, 3, 1, 0, 4}) {
@@ -269,8 +269,8 @@ void pack_painn(ti_handle* h, const float* wts)
                 }
             const int real = end_stream(o).nch;   // an odd count gets one pad chunk, which the kernels swallow once per row block
             pad_even(o);
-            (which == 0 ? h->st_jvp_w : h->st_jvp_phi).push_back(end_stream(o));
-            if (which == 0) h->jvp_w_pad.push_back(real & 1); else h->jvp_phi_pad.push_back(real & 1);
+            h->st_jvp_phi.push_back(end_stream(o));
+            h->jvp_phi_pad.push_back(real & 1);
         }
         o = begin_stream();                          // tangent update kernel: same order, V and U once per spatial component
         for (int c = 0; c < 3; ++c) layer16(h->V[l], F, F, 0);
@@ -350,8 +350,10 @@ void ensure_jvp_ws(ti_handle* h, long long B, int D)
     const long long VB = jvp_virtual_molecules(h, B, D);
     const size_t A = h->d.n_atoms, F = h->d.n_features, N = (size_t)VB * A;
     const size_t pgroups = ((size_t)B + h->G - 1) / h->G;
-    const size_t wq_floats = std::max<size_t>(pgroups * h->nblk * 5 * h->NB * 4 * 64 * 4, 4);
+    const size_t wq_floats = std::max<size_t>(pgroups * h->nblk * 5 * h->NB * 6 * 64 * 4, 4);
+    const size_t st_floats = std::max<size_t>(pgroups * h->nblk * 4 * (2 * h->NB) * 64 * 4, 4);
     if (h->wq.n < wq_floats) h->wq.alloc(wq_floats);
+    if (h->phist.n < st_floats) h->phist.alloc(st_floats);
     if (VB <= h->jvp_cap) return;
     if (N >= ((size_t)1 << 31)) throw std::invalid_argument("too many tangent nodes in one pass (lower TI_JVP_WS_GB)");
     const size_t groups = (size_t)VB / h->G;
@@ -420,10 +422,10 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         if (jr && h->nblk > 0) {
             {
                 JvpFilterParams p{};
-                p.stream = h->S(h->st_jvp_w[l]); p.nch = h->st_jvp_w[l].nch; p.pad = h->jvp_w_pad[l]; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
-                p.rows = h->rows.p; p.nblk = h->nblk; p.G = h->G; p.A = A; p.first = l == 0; p.last = l == L - 1;
-                p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale; p.x = x_dev;
-                p.wq = reinterpret_cast<float4*>(h->wq.p);
+                p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
+                p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.nblk = h->nblk; p.G = h->G; p.A = A; p.first = l == 0; p.last = l == L - 1;
+                p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale; p.x = x_dev; p.P = h->P.p; p.e = h->e.p;
+                p.wq = reinterpret_cast<float4*>(h->wq.p); p.st = reinterpret_cast<float4*>(h->phist.p);
                 Timed tm(h, TI_KERNEL_PAINN_JVP_FILTER);
                 HIP_CHECK(launch_jvp_filter(NB, split, p, st));
             }
@@ -433,7 +435,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             p.nblk = h->nblk; p.G = h->G; p.A = A; p.D = jr->D; p.first = l == 0; p.last = l == L - 1;
             p.B = B; p.n_groups = vgroups;
             p.x = x_dev; p.xdot = jr->xdot; p.P = h->P.p; p.v = h->v.p; p.e = h->e.p; p.wq = reinterpret_cast<const float4*>(h->wq.p);
-            p.tP = h->tP.p; p.tv = h->tv.p;
+            p.st = reinterpret_cast<const float4*>(h->phist.p); p.tP = h->tP.p; p.tv = h->tv.p;
             p.te = h->te.p; p.tdsacc = h->tdsacc.p; p.tdvacc = h->tdvacc.p; p.tcacc = h->tcacc.p;
             Timed tm(h, TI_KERNEL_PAINN_JVP_EDGE);
             HIP_CHECK(launch_jvp_edge(NB, split, p, st));

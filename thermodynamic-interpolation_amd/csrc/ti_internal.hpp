@@ -79,14 +79,15 @@ hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
 // ---- forward-mode derivative of the drift (painn_jvp_kernels.hip; virtual-molecule layout described there).
 // D = 3A and xdot == NULL: unit seeds (direction d -> atom d/3, component d%3); D = 1 with xdot [B*A][3]: that direction.
 // Tangent arrays are laid out like their primal twins over ceil(B/G)*D*G virtual molecules; primal arrays are read only.
-struct JvpFilterParams {                    // w_o and d w_o / d|r| of every primal edge of one layer
-    const float4* stream; int nch, pad; const float* vecs;      // pad: the stream ends with one pad chunk per row block
+struct JvpFilterParams {                    // primal pass of one layer's message block (painn_jvp_filter_kernel)
+    const float4* stream; int nch; const float* vecs; const float* edge_emb;      // the primal edge stream / vector block
     const uint32_t* rows;
     int nblk, G, A, first, last;
     long long B, n_groups;                  // molecules, primal groups
     float length_scale;
-    const float* x;
-    float4* wq;                             // [n_groups*nblk][5][NB][4][64] float4
+    const float *x, *P, *e;
+    float4* wq;                             // [n_groups*nblk][5][NB][6][64] float4: phi_o, w_o, d w_o / d|r|
+    float4* st;                             // [n_groups*nblk][4][NBK][64]   float4: LayerNorm statistics of phi
 };
 struct JvpEdgeParams {
     const float4* stream; int nch, pad; const float* vecs; const float* edge_emb;
@@ -95,7 +96,7 @@ struct JvpEdgeParams {
     long long B, n_groups;                  // molecules, VIRTUAL groups (= primal groups * D)
     const float *x, *xdot;
     const float *P, *v, *e;                 // primal state entering this layer's message block
-    const float4* wq;                       // filter pass output of this layer
+    const float4 *wq, *st;                  // primal pass output of this layer
     const float *tP, *tv;                   // tangents of P and v
     float *te, *tdsacc, *tdvacc, *tcacc;    // tangent of e (updated in place), tangent accumulators (+=)
 };
