@@ -420,11 +420,17 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
     }
 }
 
-// ================================================================================================== tangent update kernel
-// Runs BEFORE the primal update kernel of the same layer: reads the primal s, v and the three primal accumulators as the
-// edge kernel left them (read only) and advances ts, tv, tP; the tangent accumulators are consumed and zeroed.
+// ================================================================================================== primal node pass
+// Everything the per-direction update kernel needs from the forward pass of this layer's update block, ONCE per primal node
+// (16 nodes per wave, chain layout: float4 = features 16 nb + 4 (lane >> 4) .. + 3 of node row (lane & 15)):
+//   ns[((tile * NS_COUNT + which) * NBK + nb) * 64 + lane],  tile = node / 16,  which:
+//     0..2 vv_c / |vv|   (c = x, y, z; vv = V v_eff; 0 where |vv| = 0 like torch.norm's backward)
+//     3    |vv|          4..7 n, kk of the update MLP's two LayerNorms      8 scale_squared_norm output   9 gates
+//     10..12 U v_eff
+// Runs after the primal edge kernel and before the primal update kernel of the layer (reads what the latter overwrites).
+constexpr int NS_COUNT = 13;
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdateParams p)
+__global__ __launch_bounds__(256, 1) void painn_jvp_node_kernel(const JvpNodeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -437,136 +443,302 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
     PipeDMA<NB, T, 2> pipe;
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
+    const long long tile = (long long)blockIdx.x * WAVES + wave;
+    const long long node = tile * 16 + j;
+    const bool tile_ok = tile * 16 < p.N;
+    const size_t pn = (size_t)(node < p.N ? node : p.N - 1);
+    const float *vb = p.v + pn * 3 * F, *db = p.dvacc + pn * 3 * F, *cb = p.cacc + pn * 3 * F, *sb = p.s + pn * F, *ab = p.dsacc + pn * F;
+    f32x4* nsp = reinterpret_cast<f32x4*>(p.ns) + ((size_t)(tile_ok ? tile : 0) * NS_COUNT * NBK) * 64 + lane;
+    auto park = [&](int which, const A16& v) {
+        if (tile_ok) {
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) nsp[(size_t)(which * NBK + nb) * 64] = v.b[nb];
+        }
+    };
+    auto veff = [&](int c, A16& t) {
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+            const f32x4 vc = r16::load_block(vb + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
+            const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
+            const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
+            t.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);
+        }
+    };
+    // ---- phase A: vv_c = V v_eff_c (parked raw, normalised at the end of the phase), n2 = |vv|^2
+    A16 n2;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) n2.b[nb] = Z4;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        OP ve;
+        {
+            A16 t;
+            veff(c, t);
+            ve.set(t);
+        }
+        A16 vv;
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = Z4, a1 = Z4;
+            r16::gemm_bt(a0, a1, ve, wl, lane);
+            vv.b[2 * ch] = a0; vv.b[2 * ch + 1] = a1;
+            n2.b[2 * ch] += a0 * a0; n2.b[2 * ch + 1] += a1 * a1;
+            pipe.release();
+        }
+        park(c, vv);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n2.b[nb][r] = sqrtf(n2.b[nb][r]);
+    park(3, n2);
+    if (tile_ok) {                                 // vv_c <- vv_c / |vv| in place (same lane wrote it)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+                f32x4 v = nsp[(size_t)(c * NBK + nb) * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = n2.b[nb][r] > 0.f ? v[r] / n2.b[nb][r] : 0.f;
+                nsp[(size_t)(c * NBK + nb) * 64] = v;
+            }
+    }
+    // ---- phase B: MLP([ |vv| , s + ds ]) with parked LayerNorm statistics
+    OP h2;
+    {
+        A16 t;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) t.b[nb] = r16::load_block(vec + UV::B0 * F, nb, q);
+        {
+            OP nn;
+            nn.set(n2);
+#pragma unroll
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], nn, wl, lane);
+                pipe.release();
+            }
+        }
+        {
+            OP ss;
+            {
+                A16 x;
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb) x.b[nb] = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);
+                ss.set(x);
+            }
+#pragma unroll
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], ss, wl, lane);
+                pipe.release();
+            }
+        }
+        {
+            A16 nn, kk;
+            r16::ln_silu_stats(t, nn, kk, vec + UV::G0 * F, vec + UV::BE0 * F, q);
+            park(4, nn); park(5, kk);
+        }
+        {
+            OP h1;
+            h1.set(t);
+#pragma unroll
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                f32x4 a0 = r16::load_block(vec + UV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B1 * F, 2 * ch + 1, q);
+                r16::gemm_bt(a0, a1, h1, wl, lane);
+                t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1;
+                pipe.release();
+            }
+        }
+        {
+            A16 nn, kk;
+            r16::ln_silu_stats(t, nn, kk, vec + UV::G1 * F, vec + UV::BE1 * F, q);
+            park(6, nn); park(7, kk);
+        }
+        h2.set(t);
+    }
+    {   // scale_squared_norm (the add_invariant chunk is skipped: it enters no tangent), then gates
+        A16 qq, gg;
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 q0 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch, q), q1 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch + 1, q);
+            r16::gemm_bt(q0, q1, h2, wl, lane);
+            qq.b[2 * ch] = q0; qq.b[2 * ch + 1] = q1;
+            pipe.release();
+            (void)pipe.acquire();
+            pipe.release();
+        }
+        park(8, qq);
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(vec + UV::B2 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B2 * F, 2 * ch + 1, q);
+            r16::gemm_bt(a0, a1, h2, wl, lane);
+            gg.b[2 * ch] = a0; gg.b[2 * ch + 1] = a1;
+            pipe.release();
+        }
+        park(9, gg);
+    }
+    // ---- phase C: U v_eff
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        OP ve;
+        {
+            A16 t;
+            veff(c, t);
+            ve.set(t);
+        }
+        A16 uv;
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = Z4, a1 = Z4;
+            r16::gemm_bt(a0, a1, ve, wl, lane);
+            uv.b[2 * ch] = a0; uv.b[2 * ch + 1] = a1;
+            pipe.release();
+        }
+        park(10 + c, uv);
+    }
+}
+
+// ================================================================================================== tangent update kernel
+// Runs BEFORE the primal update kernel of the same layer: reads the primal v and cacc as the edge kernel left them and the
+// primal node pass output, advances ts, tv, tP; the tangent accumulators are consumed and zeroed.  Tangent products only.
+template <int NBK, bool SPLIT>
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kernel(const JvpUpdateParams p)
+{
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    using A16 = r16::Act<NBK>;
+    using OP = r16::Opnd<NBK, SPLIT>;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    PipeDMA<NB, T, 2> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+
     const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;      // virtual node
     const long long nd = node < p.N ? node : p.N - 1;
     const long long vm = nd / p.A, vg = vm / p.G;
     const long long pm_raw = (vg / p.D) * p.G + (vm - vg * p.G);                      // molecule of this virtual molecule
     const bool ok = node < p.N && pm_raw < p.B;
     const size_t pn = (size_t)((pm_raw < p.B ? pm_raw : p.B - 1) * p.A + (nd - vm * p.A));   // primal node
-    const float *vb = p.v + pn * 3 * F, *db = p.dvacc + pn * 3 * F, *cb = p.cacc + pn * 3 * F, *sb = p.s + pn * F, *ab = p.dsacc + pn * F;
+    const float *vb = p.v + pn * 3 * F, *cb = p.cacc + pn * 3 * F;
     float *tvb = p.tv + (size_t)nd * 3 * F, *tdb = p.tdvacc + (size_t)nd * 3 * F, *tcb = p.tcacc + (size_t)nd * 3 * F;
     float *tsb = p.ts + (size_t)nd * F, *tab = p.tdsacc + (size_t)nd * F;
+    // node-pass data of THIS lane's primal node: tile pn / 16, row pn % 16, this lane's feature quarter q
+    const f32x4* nsp = reinterpret_cast<const f32x4*>(p.ns) + ((pn >> 4) * NS_COUNT * NBK) * 64 + (q * 16 + (pn & 15));
+    auto stat = [&](int which, int nb) { return nsp[(size_t)(which * NBK + nb) * 64]; };
 
-    // v_eff = v + dvacc + cacc x v and its tangent for component c, one 16-feature block
-    auto veff = [&](int c, int nb, f32x4& val, f32x4& tan) {
-        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-        const f32x4 vc = r16::load_block(vb + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
-        const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
-        const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
-        val = (vc + dd) + (k1 * v2 - k2 * v1);
-        const f32x4 tvc = r16::load_block(tvb + c * F, nb, q), tdd = r16::load_block(tdb + c * F, nb, q);
-        const f32x4 tv1 = r16::load_block(tvb + c1 * F, nb, q), tv2 = r16::load_block(tvb + c2 * F, nb, q);
-        const f32x4 tk1 = r16::load_block(tcb + c1 * F, nb, q), tk2 = r16::load_block(tcb + c2 * F, nb, q);
-        tan = (tvc + tdd) + ((tk1 * v2 + k1 * tv2) - (tk2 * v1 + k2 * tv1));
-    };
-
-    // ---- phase A: n2 = |V v_eff|^2, nd2 = (V v_eff).(V tv_eff); tv_eff is parked in tdvacc.  One spatial component at a
-    // time (the tangent stream repeats the V chunks per component): two live operand sets instead of six.
-    A16 n2, nd2;
+    // ---- phase A: tv_eff (parked in tdvacc), n' = sum_c (vv_c / |vv|) . (V tv_eff_c)
+    A16 tn;
 #pragma unroll
-    for (int nb = 0; nb < NBK; ++nb) { n2.b[nb] = Z4; nd2.b[nb] = Z4; }
+    for (int nb = 0; nb < NBK; ++nb) tn.b[nb] = Z4;
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
-        OP ve, tve;
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        OP tve;
         {
-            A16 t, u;
+            A16 u;
 #pragma unroll
-            for (int nb = 0; nb < NBK; ++nb) veff(c, nb, t.b[nb], u.b[nb]);
-            ve.set(t); tve.set(u);
-            // park tv_eff[c] in tdvacc[c]: of the tangent accumulators only tdvacc[c] itself fed this component
-#pragma unroll
-            for (int nb = 0; nb < NBK; ++nb) if (ok) r16::store_block(tdb + c * F, nb, q, u.b[nb]);
+            for (int nb = 0; nb < NBK; ++nb) {
+                const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
+                const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
+                const f32x4 tvc = r16::load_block(tvb + c * F, nb, q), tdd = r16::load_block(tdb + c * F, nb, q);
+                const f32x4 tv1 = r16::load_block(tvb + c1 * F, nb, q), tv2 = r16::load_block(tvb + c2 * F, nb, q);
+                const f32x4 tk1 = r16::load_block(tcb + c1 * F, nb, q), tk2 = r16::load_block(tcb + c2 * F, nb, q);
+                u.b[nb] = (tvc + tdd) + ((tk1 * v2 + k1 * tv2) - (tk2 * v1 + k2 * tv1));
+                if (ok) r16::store_block(tdb + c * F, nb, q, u.b[nb]);      // of the accumulators only tdvacc[c] fed this component
+            }
+            tve.set(u);
         }
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();
-            f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4;
-            r16::gemm_bt2(a0, a1, b0, b1, ve, tve, wl, lane);
-            n2.b[2 * ch] += a0 * a0; n2.b[2 * ch + 1] += a1 * a1;
-            nd2.b[2 * ch] += a0 * b0; nd2.b[2 * ch + 1] += a1 * b1;
+            f32x4 b0 = Z4, b1 = Z4;
+            r16::gemm_bt(b0, b1, tve, wl, lane);
+            tn.b[2 * ch] += stat(c, 2 * ch) * b0; tn.b[2 * ch + 1] += stat(c, 2 * ch + 1) * b1;
             pipe.release();
         }
     }
-    // |vv| and its tangent, in place: n2 <- n, nd2 <- n'
-#pragma unroll
-    for (int nb = 0; nb < NBK; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float n = sqrtf(n2.b[nb][r]);
-            nd2.b[nb][r] = n > 0.f ? nd2.b[nb][r] / n : 0.f;
-            n2.b[nb][r] = n;
-        }
-    // ---- phase B: MLP([ |vv| , s + ds ])
-    OP h2, th2;
+    // ---- phase B: tangent of MLP([ |vv| , s + ds ])
+    OP th2;
     {
-        A16 t, u;
+        A16 u;
 #pragma unroll
-        for (int nb = 0; nb < NBK; ++nb) { t.b[nb] = r16::load_block(vec + UV::B0 * F, nb, q); u.b[nb] = Z4; }
+        for (int nb = 0; nb < NBK; ++nb) u.b[nb] = Z4;
         {
-            OP nn, tnn;
-            nn.set(n2); tnn.set(nd2);
+            OP tnn;
+            tnn.set(tn);
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
-                r16::gemm_bt2(t.b[2 * ch], t.b[2 * ch + 1], u.b[2 * ch], u.b[2 * ch + 1], nn, tnn, wl, lane);
+                r16::gemm_bt(u.b[2 * ch], u.b[2 * ch + 1], tnn, wl, lane);
                 pipe.release();
             }
         }
         {
-            OP ss, tss;
+            OP tss;
             {
-                A16 x, y;
+                A16 y;
 #pragma unroll
-                for (int nb = 0; nb < NBK; ++nb) {
-                    x.b[nb] = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);
-                    y.b[nb] = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
-                }
-                ss.set(x); tss.set(y);
+                for (int nb = 0; nb < NBK; ++nb) y.b[nb] = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
+                tss.set(y);
             }
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
-                r16::gemm_bt2(t.b[2 * ch], t.b[2 * ch + 1], u.b[2 * ch], u.b[2 * ch + 1], ss, tss, wl, lane);
+                r16::gemm_bt(u.b[2 * ch], u.b[2 * ch + 1], tss, wl, lane);
                 pipe.release();
             }
         }
-        r16::ln_silu_dual(t, u, vec + UV::G0 * F, vec + UV::BE0 * F, q);
         {
-            OP h1, th1;
-            h1.set(t); th1.set(u);
+            A16 nn, kk;
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) { nn.b[nb] = stat(4, nb); kk.b[nb] = stat(5, nb); }
+            r16::ln_tangent(u, nn, kk);
+        }
+        {
+            OP th1;
+            th1.set(u);
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
-                f32x4 a0 = r16::load_block(vec + UV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B1 * F, 2 * ch + 1, q);
                 f32x4 b0 = Z4, b1 = Z4;
-                r16::gemm_bt2(a0, a1, b0, b1, h1, th1, wl, lane);
-                t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
+                r16::gemm_bt(b0, b1, th1, wl, lane);
+                u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
                 pipe.release();
             }
         }
-        r16::ln_silu_dual(t, u, vec + UV::G1 * F, vec + UV::BE1 * F, q);
-        h2.set(t); th2.set(u);
+        {
+            A16 nn, kk;
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) { nn.b[nb] = stat(6, nb); kk.b[nb] = stat(7, nb); }
+            r16::ln_tangent(u, nn, kk);
+        }
+        th2.set(u);
     }
-    // ---- output chunks: [scale_squared_norm, add_invariant] per 32-feature block, then gates
+    // ---- output chunks: ts += 2 n n' q + n^2 q' + add'
 #pragma unroll
     for (int ch = 0; ch < NB; ++ch) {
         const f32x4* wl = pipe.acquire();
-        f32x4 q0 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch, q), q1 = r16::load_block(vec + (UV::B2 + 1) * F, 2 * ch + 1, q);
         f32x4 tq0 = Z4, tq1 = Z4;
-        r16::gemm_bt2(q0, q1, tq0, tq1, h2, th2, wl, lane);
+        r16::gemm_bt(tq0, tq1, th2, wl, lane);
         pipe.release();
         wl = pipe.acquire();
-        f32x4 ta0 = Z4, ta1 = Z4;                      // the primal `add` term does not enter any tangent
+        f32x4 ta0 = Z4, ta1 = Z4;
         r16::gemm_bt(ta0, ta1, th2, wl, lane);
         pipe.release();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int nb = 2 * ch + k;
             f32x4 so = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
-            const f32x4 qq = k ? q1 : q0, tqq = k ? tq1 : tq0, taa = k ? ta1 : ta0;
+            const f32x4 tqq = k ? tq1 : tq0, taa = k ? ta1 : ta0, nrm = stat(3, nb), qq = stat(8, nb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float n = n2.b[nb][r], dn = nd2.b[nb][r];
+                const float n = nrm[r], dn = tn.b[nb][r];
                 so[r] = so[r] + (((2.0f * n) * dn) * qq[r] + (n * n) * tqq[r] + taa[r]);
             }
             if (ok) {
@@ -575,43 +747,34 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_update_kernel(const JvpUpdat
             }
         }
     }
-    A16 gg, tgg;
+    A16 tgg;
 #pragma unroll
     for (int ch = 0; ch < NB; ++ch) {
         const f32x4* wl = pipe.acquire();
-        f32x4 a0 = r16::load_block(vec + UV::B2 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::B2 * F, 2 * ch + 1, q);
         f32x4 b0 = Z4, b1 = Z4;
-        r16::gemm_bt2(a0, a1, b0, b1, h2, th2, wl, lane);
-        gg.b[2 * ch] = a0; gg.b[2 * ch + 1] = a1; tgg.b[2 * ch] = b0; tgg.b[2 * ch + 1] = b1;
+        r16::gemm_bt(b0, b1, th2, wl, lane);
+        tgg.b[2 * ch] = b0; tgg.b[2 * ch + 1] = b1;
         pipe.release();
     }
-    // ---- phase C: tv = tv_eff + (U tv_eff) gates + (U v_eff) tgates, one component at a time (U chunks repeated per component)
+    // ---- phase C: tv = tv_eff + (U tv_eff) gates + (U v_eff) tgates
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
-        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-        OP ve, tve;
+        OP tve;
         {
-            A16 t, u;
-#pragma unroll
-            for (int nb = 0; nb < NBK; ++nb) {
-                const f32x4 vc = r16::load_block(vb + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
-                const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
-                const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
-                t.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);
-                u.b[nb] = r16::load_block(tdb + c * F, nb, q);
-            }
-            ve.set(t); tve.set(u);
+            A16 u;
+            r16::load_set(u, tdb + c * F, q);
+            tve.set(u);
         }
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();
-            f32x4 a0 = Z4, a1 = Z4, b0 = Z4, b1 = Z4;
-            r16::gemm_bt2(a0, a1, b0, b1, ve, tve, wl, lane);
+            f32x4 b0 = Z4, b1 = Z4;
+            r16::gemm_bt(b0, b1, tve, wl, lane);
             pipe.release();
             const f32x4 e0 = r16::load_block(tdb + c * F, 2 * ch, q), e1 = r16::load_block(tdb + c * F, 2 * ch + 1, q);
             if (ok) {
-                r16::store_block(tvb + c * F, 2 * ch, q, e0 + (b0 * gg.b[2 * ch] + a0 * tgg.b[2 * ch]));
-                r16::store_block(tvb + c * F, 2 * ch + 1, q, e1 + (b1 * gg.b[2 * ch + 1] + a1 * tgg.b[2 * ch + 1]));
+                r16::store_block(tvb + c * F, 2 * ch, q, e0 + (b0 * stat(9, 2 * ch) + stat(10 + c, 2 * ch) * tgg.b[2 * ch]));
+                r16::store_block(tvb + c * F, 2 * ch + 1, q, e1 + (b1 * stat(9, 2 * ch + 1) + stat(10 + c, 2 * ch + 1) * tgg.b[2 * ch + 1]));
                 r16::store_block(tdb + c * F, 2 * ch, q, Z4);
                 r16::store_block(tdb + c * F, 2 * ch + 1, q, Z4);
             }
@@ -767,6 +930,8 @@ static hipError_t configure_jvp_nbk(int NB)
     if ((e = set_lds(painn_jvp_filter_kernel<NBK, true>, jvp_node_lds(NB, EV::COUNT))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_edge_kernel<NBK, false>, jvp_edge_lds(NB))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_edge_kernel<NBK, true>, jvp_edge_lds(NB))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_node_kernel<NBK, false>, jvp_node_lds(NB, UV::COUNT))) != hipSuccess) return e;
+    if ((e = set_lds(painn_jvp_node_kernel<NBK, true>, jvp_node_lds(NB, UV::COUNT))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_update_kernel<NBK, false>, jvp_node_lds(NB, UV::COUNT))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_update_kernel<NBK, true>, jvp_node_lds(NB, UV::COUNT))) != hipSuccess) return e;
     if ((e = set_lds(painn_jvp_readout_kernel<NBK, false>, jvp_node_lds(NB, RV::COUNT))) != hipSuccess) return e;
@@ -798,6 +963,17 @@ hipError_t launch_jvp_edge(int NBv, bool split, const JvpEdgeParams& p, hipStrea
     TI_JVP_DISPATCH(NBv, {
         if (split) hipLaunchKernelGGL((painn_jvp_edge_kernel<NBK, true>), g, dim3(256), l, st, p);
         else hipLaunchKernelGGL((painn_jvp_edge_kernel<NBK, false>), g, dim3(256), l, st, p);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_jvp_node(int NBv, bool split, const JvpNodeParams& p, hipStream_t st)
+{
+    const dim3 g((unsigned)((p.N + 63) / 64));
+    const size_t l = jvp_node_lds(NBv, UV::COUNT);
+    TI_JVP_DISPATCH(NBv, {
+        if (split) hipLaunchKernelGGL((painn_jvp_node_kernel<NBK, true>), g, dim3(256), l, st, p);
+        else hipLaunchKernelGGL((painn_jvp_node_kernel<NBK, false>), g, dim3(256), l, st, p);
     });
     return hipGetLastError();
 }

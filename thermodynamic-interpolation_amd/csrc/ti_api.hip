@@ -123,7 +123,7 @@ struct ti_handle {
     int tap = -1; long long last_B = 0;
     // forward-mode derivative (painn_jvp_kernels.hip): tangent twins over virtual molecules, sized on first use
     std::vector<Stream> st_jvp_update, st_jvp_phi; Stream st_jvp_readout{}; std::vector<int> jvp_phi_pad;
-    DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, wq, phist, divb, dl, dlscaled, div2;
+    DevBuf<float> jvp_ro_vecs, ts, tP, tv, tdsacc, tdvacc, tcacc, te, tout, wq, phist, nodest, divb, dl, dlscaled, div2;
     long long jvp_cap = 0, last_VB = 0; int last_D = 1;
     // Runge-Kutta drivers (rollout_rk): stage derivatives, dense-output coefficients, reduction scratch
     DevBuf<float> rk_ws; DevBuf<double> rk_red;
@@ -354,6 +354,8 @@ void ensure_jvp_ws(ti_handle* h, long long B, int D)
     const size_t st_floats = std::max<size_t>(pgroups * h->nblk * 4 * (2 * h->NB) * 64 * 4, 4);
     if (h->wq.n < wq_floats) h->wq.alloc(wq_floats);
     if (h->phist.n < st_floats) h->phist.alloc(st_floats);
+    const size_t ns_floats = (((size_t)B * A + 15) / 16) * 13 * (2 * h->NB) * 64 * 4;
+    if (h->nodest.n < ns_floats) h->nodest.alloc(ns_floats);
     if (VB <= h->jvp_cap) return;
     if (N >= ((size_t)1 << 31)) throw std::invalid_argument("too many tangent nodes in one pass (lower TI_JVP_WS_GB)");
     const size_t groups = (size_t)VB / h->G;
@@ -451,10 +453,18 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         }
         if (h->tap == 1 + 2 * l) return;
         if (jr) {
+            {
+                JvpNodeParams p{};
+                p.stream = h->S(h->st_jvp_update[l]); p.nch = h->st_jvp_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
+                p.N = N; p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p;
+                p.ns = reinterpret_cast<float4*>(h->nodest.p);
+                Timed tm(h, TI_KERNEL_PAINN_JVP_FILTER);
+                HIP_CHECK(launch_jvp_node(NB, split, p, st));
+            }
             JvpUpdateParams p{};
             p.stream = h->S(h->st_jvp_update[l]); p.nch = h->st_jvp_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
             p.N = VN; p.B = B; p.A = A; p.D = jr->D; p.G = h->G; p.has_next = l + 1 < L;
-            p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p;
+            p.v = h->v.p; p.cacc = h->cacc.p; p.ns = reinterpret_cast<const float4*>(h->nodest.p);
             p.ts = h->ts.p; p.tv = h->tv.p; p.tdsacc = h->tdsacc.p; p.tdvacc = h->tdvacc.p; p.tcacc = h->tcacc.p; p.tP = h->tP.p;
             Timed tm(h, TI_KERNEL_PAINN_JVP_UPDATE);
             HIP_CHECK(launch_jvp_update(NB, split, p, st));

@@ -100,10 +100,17 @@ struct JvpEdgeParams {
     const float *tP, *tv;                   // tangents of P and v
     float *te, *tdsacc, *tdvacc, *tcacc;    // tangent of e (updated in place), tangent accumulators (+=)
 };
+struct JvpNodeParams {                      // primal node pass of one layer's update block (painn_jvp_node_kernel)
+    const float4* stream; int nch; const float* vecs;          // the tangent update stream (V and U once per component)
+    long long N;                            // primal nodes
+    const float *s, *v, *dsacc, *dvacc, *cacc;
+    float4* ns;                             // [ceil(N/16)][13][NBK][64] float4
+};
 struct JvpUpdateParams {
     const float4* stream; int nch; const float* vecs;
     long long N, B; int A, D, G, has_next;  // N virtual nodes
-    const float *s, *v, *dsacc, *dvacc, *cacc;                  // primal, as the primal edge kernel left them
+    const float *v, *cacc;                  // primal, as the primal edge kernel left them
+    const float4* ns;                       // primal node pass output of this layer
     float *ts, *tv, *tdsacc, *tdvacc, *tcacc, *tP;
 };
 struct JvpReadoutParams {
@@ -114,6 +121,7 @@ struct JvpReadoutParams {
 };
 hipError_t launch_jvp_filter(int NB, bool split, const JvpFilterParams& p, hipStream_t st);
 hipError_t launch_jvp_edge(int NB, bool split, const JvpEdgeParams& p, hipStream_t st);
+hipError_t launch_jvp_node(int NB, bool split, const JvpNodeParams& p, hipStream_t st);
 hipError_t launch_jvp_update(int NB, bool split, const JvpUpdateParams& p, hipStream_t st);
 hipError_t launch_jvp_readout(int NB, bool split, const JvpReadoutParams& p, hipStream_t st);
 hipError_t launch_div_reduce(const float* tout, long long B, int D, int G, float* div, hipStream_t st);
