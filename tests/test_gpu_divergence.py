@@ -145,3 +145,27 @@ def test_molecule_integrator_return_dlogp(name):
         assert rel_l2(xts.numpy() - ref[0], ref - ref[0]) < 2e-5
         ref_dl = g[f"dlogp_{tag}"] * out_scale
         assert np.allclose(dlogp.numpy(), ref_dl, rtol=0, atol=DIV_ATOL * (np.abs(ref_dl).max() + 1.0))
+
+
+@pytest.mark.parametrize("F,L,A,B,variant,precision", [(256, 2, 5, 3, 0, "f32"), (256, 2, 5, 3, 0, "f16x2"), (64, 3, 25, 2, 1, "f32"),
+                                                       (32, 2, 2, 7, 2, "f32"), (64, 2, 1, 4, 0, "f32")])
+def test_divergence_other_widths_and_sizes_vs_oracle(F, L, A, B, variant, precision):
+    """F = 256 (one workgroup per CU path), the largest molecule (25 atoms, 600 edges), a diatomic, and a single atom with no
+    edges at all (the drift and its divergence vanish: v stays 0)."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(variant, F, L, 25, seed=F + A), W.painn_param_spec(variant, F, L, 25))
+    x = syn.molecule_coords(B, A, seed=B)
+    cond = [syn.ambient_cond(B, A), syn.latent_cond(B, A, 500.0), None][variant]
+    kw = dict(temp_length=100.0 if variant == 0 else 75.0)
+    eng = ti.engine.PainnEngine(variant, F, L, A, src, dst, et, np.arange(A), flat, precision=precision, **kw)
+    orc = oracle.PainnOracle(variant, F, L, A, src, dst, et, np.arange(A), flat, **kw)
+    b, div = eng.drift_div(x, 0.37, cond)
+    ob, odiv = orc.drift_div(x, 0.37, cond, precision=64)
+    assert np.isfinite(div).all()
+    if A == 1:
+        assert np.abs(b).max() == 0.0 and np.abs(div).max() == 0.0 and np.abs(odiv).max() == 0.0
+        return
+    assert rel_l2(b, ob) < TOL
+    assert (np.abs(div - odiv) < DIV_ATOL * (np.abs(odiv) + 1.0)).all(), (div, odiv)
