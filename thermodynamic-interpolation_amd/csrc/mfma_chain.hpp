@@ -618,6 +618,36 @@ __device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd<NBK
 template <int NBK>
 __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK, false>& in, const f32x4* wl, int lane) { gemm_fl(acc0, acc1, in.a, wl, lane); }
 
+// ---- per-slot row sums of a flipped-layout block as a 16x16 selection product  S[slot][n] = sum_row Sel[slot][row] val[row][n].
+// sel[r] (A operand: lane (slot, q) holds row 4q + r) is 1 where the row's destination is that slot; val (B operand) is the
+// accumulator layout itself (lane (n, q) holds rows 4q + r).  Exact products, fixed summation order -> deterministic.
+// f32: four 16x16x4 products (32 matrix cycles each).  Split mode: the values go through the fp16 pipe as hi + 2^-11 lo, the
+// 0/1 selector is exact in fp16: two 16x16x16 products instead -- the selection sums were a quarter of the split kernel's
+// matrix cycles.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 select_sum(const f32x4& sel, const f32x4& v)
+{
+    if (SPLIT) {
+        h4 sh, hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sh[r] = (_Float16)sel[r];
+            const _Float16 h = (_Float16)v[r];
+            hi[r] = h;
+            lo[r] = (_Float16)((v[r] - (float)h) * 2048.0f);
+        }
+        const f32x4 z = {0, 0, 0, 0};
+        const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x16f16(sh, hi, z, 0, 0, 0);
+        const f32x4 b = __builtin_amdgcn_mfma_f32_16x16x16f16(sh, lo, z, 0, 0, 0);
+        return a + b * 4.8828125e-4f;
+    }
+    f32x4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = mfma16(sel[r], v[r], s);
+    return s;
+}
+
 // ---- (value, tangent) operand pairs against one weight chunk: every LDS fragment is read once for both products
 template <int NBK, bool FLIP>
 __device__ __forceinline__ void gemm_pair_f32(f32x4& a0, f32x4& a1, f32x4& t0, f32x4& t1, const Act<NBK>& in, const Act<NBK>& tin,

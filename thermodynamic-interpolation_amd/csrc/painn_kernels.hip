@@ -256,9 +256,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
         };
         // add the per-slot sums of (v0 | v1) into dst[node*stride + {0,16}] (dst already offset to component / feature)
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
-            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s0 = r16::mfma16(sel[r], v0[r], s0); s1 = r16::mfma16(sel[r], v1[r], s1); }
+            const f32x4 s0 = r16::select_sum<SPLIT>(sel, v0), s1 = r16::select_sum<SPLIT>(sel, v1);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (snode[r] >= 0) { float* d = dst + (size_t)snode[r] * stride; add_noret(d, s0[r]); add_noret(d + 16, s1[r]); }
