@@ -11,4 +11,4 @@ timeout -k 10 900 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_ou
 timeout -k 10 900 python bench.py > gpurun_out/bench_full.log 2>&1
 rc=$?; echo "BENCH_EXIT=$rc"; tail -1 gpurun_out/bench_full.log | cut -c1-300
 if [ $rc -ne 0 ]; then exit $rc; fi
-BENCH_ARGS="--no-f32-leg" ./tools_gpu_prof.sh $TAG
+BENCH_ARGS="--no-f32-leg" tools/gpu_prof.sh $TAG

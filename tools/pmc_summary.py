@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 PMC passes (gpurun_out/pmc_<tag>_*) per kernel: usage  tools_pmc_summary.py <tag> [out.md]"""
+"""Summarise rocprofv3 PMC passes (gpurun_out/pmc_<tag>_*) per kernel: usage  tools/pmc_summary.py <tag> [out.md]"""
 import collections, csv, glob, sys
 tag = sys.argv[1]
 out = []
