@@ -87,18 +87,6 @@ def main():
                    "precision": prec, "molecule_div_evals_per_s": B / dt_div, "ms_per_eval": dt_div * 1e3,
                    "cost_ratio_vs_plain_drift": dt_div / dt_b,
                    "kernel_ms": {k: round(v[1], 3) for k, v in prof.items()}, "kernel_launches": {k: v[0] for k, v in prof.items()}}
-            if prec == "f32" and not os.environ.get("TI_BENCH_NO_CPU"):
-                from oracle import oracle                       # CPU baseline leg only (oracle/ti_oracle.c header)
-                n_cpu = 8
-                orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
-                xc, cc = syn.molecule_coords(n_cpu, A, 0), syn.ambient_cond(n_cpu, A)
-                t0 = time.perf_counter()
-                _, od = orc.drift_div(xc, 0.5, cc, precision=32)
-                t_cpu = time.perf_counter() - t0
-                _, gd = eng.drift_div(xc, 0.5, cc)
-                rec["cpu_oracle_molecule_div_evals_per_s"] = n_cpu / t_cpu
-                rec["cpu_threads"] = oracle.num_threads()
-                rec["max_abs_div_diff_vs_oracle"] = float(np.abs(gd - od).max())
             print(json.dumps(rec))
             eng.close()
 
