@@ -7,8 +7,10 @@
 //   update  : Update.forward cpainn.py:345-376, EquivariantLinear cpainn.py:403
 //   readout : LayerReadout.forward cpainn.py:425-437, cPaiNN.forward cpainn.py:112-115
 //
-// All dense layers run on v_mfma_f32_32x32x2_f32 through mfma_chain.hpp; activations never leave registers inside an
-// MLP chain; per-atom sums over incoming edges are done inside one wave in a fixed order (deterministic, no atomics).
+// Dense layers run on the matrix cores through mfma_chain.hpp (f32 32x32x2 / 16x16x4, or fp16 16x16x32 with split operands);
+// activations never leave registers inside an MLP chain; per-atom sums over incoming edges are formed per 16-row block by a
+// selection product and added to HBM accumulators with no-return atomics by the one wave that owns the molecule, in program
+// order -- deterministic without an ordered reduction tree.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "mfma_chain.hpp"

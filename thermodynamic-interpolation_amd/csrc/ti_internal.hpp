@@ -14,7 +14,7 @@ namespace ti {
 // ---- molecule-group edge template -------------------------------------------------------------------------------
 // The E_m edges of one molecule are sorted by (dst, src); G molecules form a "group" whose G*E_m edge rows are padded
 // to NBLK blocks of EDGE_ROWS_PER_BLOCK rows.  One wave owns one group, so every per-atom sum over incoming edges stays inside a wave
-// (deterministic, no atomics).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots".
+// in that wave's program order (deterministic).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots".
 //   row word : bit0 valid | mol_local<<1 (5b) | src<<6 (5b) | dst<<11 (5b) | etype<<16 (2b) | slot<<18 (6b, 63 = none)
 //   slot word: mol_local<<8 | atom     (-1 = unused)
 constexpr int ROW_VALID = 1;
