@@ -35,6 +35,24 @@ def check_reweighting(ti, x0, x1, dlogp):
         est = (w * f).sum()
         se = np.sqrt((w ** 2 * (f - est) ** 2).sum())                   # delta-method standard error of the ratio estimator
         assert abs(est - target[name]) < 5 * se + 1e-4, (name, est, target[name], se)
+    # free-energy profile  F(x) = -log p(x) / beta1  on a grid of bins (the adw end-state observable of the reference's
+    # free_energy.py): reweighted histogram against the analytic profile, up to the additive constant, within 5 standard errors
+    edges = np.linspace(-1.6, 1.6, 33)
+    idx = np.digitize(x1, edges) - 1
+    ok = (idx >= 0) & (idx < 32)
+    pw = np.bincount(idx[ok], weights=w[ok], minlength=32)
+    pw2 = np.bincount(idx[ok], weights=(w[ok] ** 2), minlength=32)
+    centres = 0.5 * (edges[1:] + edges[:-1])
+    fine = np.linspace(-1.6, 1.6, 32 * 64 + 1)
+    pt = np.exp(-BETA1 * syn.adw_potential(fine))
+    pt = 0.5 * (pt[1:] + pt[:-1])
+    pt = pt.reshape(32, 64).sum(axis=1)
+    keep = pw > 50.0 / n                                               # bins with enough effective counts
+    f_est, f_true = -np.log(pw[keep]) / BETA1, -np.log(pt[keep]) / BETA1
+    se = np.sqrt(pw2[keep]) / pw[keep] / BETA1
+    shift = np.average(f_est - f_true, weights=1.0 / se ** 2)
+    assert keep.sum() >= 20 and centres[keep].min() < -1.0 and centres[keep].max() > 1.0
+    assert (np.abs(f_est - f_true - shift) < 5 * se + 2e-3).all(), np.abs(f_est - f_true - shift) / se
     # the transport itself moves the ensemble most of the way from the base to the target
     raw = x1.mean()
     assert abs(raw - target["mean"]) < 0.35 * abs(base["mean"] - target["mean"]), (raw, base["mean"], target["mean"])
