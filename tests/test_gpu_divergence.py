@@ -169,3 +169,25 @@ def test_divergence_other_widths_and_sizes_vs_oracle(F, L, A, B, variant, precis
         return
     assert rel_l2(b, ob) < TOL
     assert (np.abs(div - odiv) < DIV_ATOL * (np.abs(odiv) + 1.0)).all(), (div, odiv)
+
+
+def test_divergence_race_screen_full_occupancy():
+    """256 molecules x 54 directions fill every CU with two workgroups of each tangent kernel.  During development the
+    split-fp16 build of the tangent readout kernel returned wrong sums for about one 16-node tile in 2 000 in exactly this
+    regime (5-10 molecules per evaluation off by 1e-3..1e-1) while every small-batch parity test passed; the f32 and split
+    builds are independent instruction streams, so per-molecule agreement of repeated evaluations of both is the screen."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    F, L, A, B = 128, 2, 18, 256
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=F + A), W.painn_param_spec(0, F, L, 25))
+    x, cond = syn.molecule_coords(B, A, seed=B), syn.ambient_cond(B, A)
+    outs = []
+    for prec in ("f32", "f16x2"):
+        eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision=prec)
+        outs += [eng.drift_div(x, 0.5, cond)[1].astype(np.float64) for _ in range(4)]
+        eng.close()
+    ref = outs[0]
+    for o in outs[1:]:
+        bad = np.abs(o - ref) > 5e-5 * (np.abs(ref) + 1.0)
+        assert not bad.any(), f"{int(bad.sum())} molecules disagree, worst {np.abs(o - ref).max():.2e}"

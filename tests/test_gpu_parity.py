@@ -155,8 +155,15 @@ def test_painn_large_batch_properties():
     perm = np.random.RandomState(2).permutation(B)
     # molecules are independent; the position inside a molecule group only changes the order of a few partial sums
     assert rel_l2(eng.drift(x[perm], 0.5, cond[perm]), b[perm]) < 5e-6
-    # a slice of the batch evaluated on its own agrees bit for bit (group/tile padding does not leak)
-    np.testing.assert_array_equal(eng.drift(x[:131], 0.5, cond[:131]), b[:131])
+    # a slice of the batch evaluated on its own (group/tile padding does not leak): bit for bit with the same edge template;
+    # a small batch alone switches to the latency template (other row blocking, same sums in another order)
+    assert rel_l2(eng.drift(x[:131], 0.5, cond[:131]), b[:131]) < 2e-6
+    import os
+    os.environ["TI_TEMPLATE"] = "throughput"
+    try:
+        np.testing.assert_array_equal(eng.drift(x[:131], 0.5, cond[:131]), b[:131])
+    finally:
+        del os.environ["TI_TEMPLATE"]
     orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
     idx = np.r_[0:3, B - 3:B]
     assert rel_l2(b[idx], orc.drift(x[idx], 0.5, cond[idx])) < DRIFT_TOL
@@ -306,3 +313,42 @@ def test_adw_standard_integrator_with_dlogp_like_the_shipped_config():
     assert rel_l2(sample.numpy()[:, :, 0], g["traj_heun"]) < 1e-5
     b, negdiv = ti.thermo.adw.ODEWrapper(net, return_dlogp=True)(0.3, (x0s, None), None, beta0s, beta1s)
     assert rel_l2(negdiv.numpy().ravel(), g["negdiv_1"].ravel()) < 1e-5
+
+
+@pytest.mark.parametrize("F,L,A,B,variant,precision", [(128, 2, 18, 50, 0, "f32"), (128, 2, 18, 50, 0, "f16x2"), (64, 2, 25, 7, 1, "f32"),
+                                                       (32, 3, 9, 33, 2, "f32"), (32, 2, 4, 5, 0, "f32")])
+def test_edge_templates_agree(F, L, A, B, variant, precision, monkeypatch):
+    """The two edge templates (ti_internal.hpp: throughput = G molecules per wave, latency = one molecule cut into parts of
+    destination atoms, one wave each) evaluate the same sums in different blockings: drift, per-stage state and divergence agree
+    with each other to round-off and with the oracle to the drift bar.  A = 4 has too few rows for a second template."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(variant, F, L, 25, seed=F + A), W.painn_param_spec(variant, F, L, 25))
+    x = syn.molecule_coords(B, A, seed=B)
+    cond = [syn.ambient_cond(B, A), syn.latent_cond(B, A, 500.0), None][variant]
+    kw = dict(temp_length=100.0 if variant == 0 else 75.0)
+    eng = ti.engine.PainnEngine(variant, F, L, A, src, dst, et, np.arange(A), flat, precision=precision, **kw)
+    orc = oracle.PainnOracle(variant, F, L, A, src, dst, et, np.arange(A), flat, **kw)
+    ref, rdiv = orc.drift_div(x, 0.4, cond, precision=64)
+    res = {}
+    for mode in ("throughput", "latency"):
+        monkeypatch.setenv("TI_TEMPLATE", mode)
+        b, div = eng.drift_div(x, 0.4, cond)
+        assert rel_l2(b, ref) < DRIFT_TOL, mode
+        assert (np.abs(div - rdiv) < 2e-5 * (np.abs(rdiv) + 1.0)).all(), mode
+        np.testing.assert_array_equal(eng.drift(x, 0.4, cond), b)
+        eng.debug_tap(1)                                     # after the first message block: the e rows go through the row map
+        try:
+            eng.drift(x, 0.4, cond)
+            _, taps = orc.drift(x, 0.4, cond, tap_stage=1)
+            if L > 1:
+                assert rel_l2(eng.debug_read("e", B), taps["e"]) < DRIFT_TOL, mode
+            assert rel_l2(eng.debug_read("s", B), taps["s"]) < DRIFT_TOL, mode
+        finally:
+            eng.debug_tap(-1)
+        path, dl, _ = eng.rollout_dlogp(x, cond, np.linspace(0, 1, 3).astype(np.float32), scheme="heun", save_every=0)
+        res[mode] = (b, div, path, dl)
+    assert rel_l2(res["latency"][0], res["throughput"][0]) < 2e-6
+    assert rel_l2(res["latency"][2], res["throughput"][2]) < 2e-6
+    assert np.abs(res["latency"][3] - res["throughput"][3]).max() < 2e-5 * (np.abs(res["throughput"][3]).max() + 1.0)

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 && !TAN) ? 2 : 1) void adw_mlp_kerne
     o = r16::xquarters(o) + p.b_out;
     if (TAN) d = r16::xquarters(d);
     if (ok && q == 0) { p.out[row] = o; if (TAN) p.out_div[row] = d; }
+    pipe.drain();
 }
 
 static size_t adw_lds_bytes(int NB, int n_hidden) { return 2 * (size_t)256 * NB * 16 + (size_t)(5 + n_hidden) * 32 * NB * 4; }

@@ -134,6 +134,14 @@ struct PipeDMA {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    // Call once at the very end of a kernel: the last release() has a prefetch in flight that nobody will consume, and an
+    // LDS-DMA still in flight when the workgroup retires lands in LDS that may already belong to the next workgroup.
+    __device__ __forceinline__ void drain() const
+    {
+#ifndef TI_NO_DRAIN
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    }
     __device__ __forceinline__ const f32x4* acquire() const { return base + par * SUP4 + sub * CH4; }
     __device__ __forceinline__ void release()
     {

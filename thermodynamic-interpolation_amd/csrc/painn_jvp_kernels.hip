@@ -6,6 +6,7 @@
 // (d perturbs atom d / 3, component d % 3) gives the Jacobian diagonal, D = 1 with an explicit xdot an arbitrary JVP.
 // They are grouped like the primal molecules: primal group pg (G molecules, one wave) and direction d form virtual group
 // vg = pg * D + d, whose G members are the G molecules of pg -- so virtual row (blk, j) IS primal row (blk, j) of group pg
+// (with P > 1 parts per group, ti_internal.hpp, every part of every direction has its own wave: gi = (pg * D + d) * P + part)
 // (same edge, same slot), and the D directions of one primal group are neighbours in the launch (their primal reads hit L2).
 //   virtual molecule vm = vg * G + m  <->  molecule pm = pg * G + m;   virtual node = vm * A + atom.
 // The kernels carry ONLY tangents in HBM (ts, tv, te, tP and three accumulators, laid out like their primal twins over
@@ -29,6 +30,19 @@
 
 #include "mfma_chain.hpp"
 #include "ti_internal.hpp"
+
+#ifndef TI_JVP_EDGE_OCC
+#define TI_JVP_EDGE_OCC 2
+#endif
+#ifndef TI_JVP_UPD_OCC
+#define TI_JVP_UPD_OCC 2
+#endif
+#ifndef TI_JVP_RO_OCC
+#define TI_JVP_RO_OCC 1
+#endif
+#ifndef TI_JVP_RO_SC
+#define TI_JVP_RO_SC 2
+#endif
 
 namespace ti {
 
@@ -77,10 +91,12 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_filter_kernel(const JvpFilte
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
     const bool first = p.first != 0, last = p.last != 0;
+    const long long mg = gi / p.parts;                                                  // molecule group; gi also counts its parts
+    const uint32_t* rows = p.rows + (size_t)(gi - mg * p.parts) * p.nblk * 16;
 
     for (int blk = 0; blk < p.nblk; ++blk) {
-        const uint32_t meta = p.rows[blk * 16 + j];
-        long long pm = gi * p.G + row_mol(meta);
+        const uint32_t meta = rows[blk * 16 + j];
+        long long pm = mg * p.G + row_mol(meta);
         pm = pm < p.B ? pm : p.B - 1;
         const long long nsrc = pm * p.A + row_src(meta), ndst = pm * p.A + row_dst(meta);
         const size_t prow0 = ((size_t)gi * p.nblk + blk) * 16;
@@ -200,13 +216,14 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_filter_kernel(const JvpFilte
             if (!first) { put(0, nbo); put(4, nbo); }
         }
     }
+    pipe.drain();
 }
 
 // ================================================================================================== tangent edge kernel
 // One wave per virtual group.  Per (edge, direction) row only TANGENT products remain: the phi branch's hidden layers and
 // output chunks applied to the tangent of [s[src] | e]; every primal quantity comes from the primal pass above.
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel(const JvpEdgeParams p)
+__global__ __launch_bounds__(256, (NBK <= 8 ? TI_JVP_EDGE_OCC : 1)) void painn_jvp_edge_kernel(const JvpEdgeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -223,14 +240,20 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;                 // virtual group
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
-    const long long pg = gi / p.D;                                                  // primal group
-    const int dsel = (int)(gi - pg * p.D);                                          // seed direction
+    // gi = (molecule group * D + direction) * P + part
+    const long long vmg = gi / p.parts;                                                 // virtual molecule group
+    const int part = (int)(gi - vmg * p.parts);
+    const long long mg = vmg / p.D;                                                 // molecule group
+    const int dsel = (int)(vmg - mg * p.D);                                         // seed direction
+    const long long pg = mg * p.parts + part;                                         // primal group (incl. part): rows of e, wq, st
+    const uint32_t* rows = p.rows + (size_t)part * p.nblk * 16;
+    const int32_t* slotnode = p.slotnode + (size_t)part * p.nblk * 16;
     const bool first = p.first != 0, last = p.last != 0;
 
     for (int blk = 0; blk < p.nblk; ++blk) {
         // ---- geometry of this lane's row and its tangent
-        const uint32_t meta = p.rows[blk * 16 + j];
-        long long pm = pg * p.G + row_mol(meta);
+        const uint32_t meta = rows[blk * 16 + j];
+        long long pm = mg * p.G + row_mol(meta);
         pm = pm < p.B ? pm : p.B - 1;
         const long long nsrc = pm * p.A + row_src(meta), ndst = pm * p.A + row_dst(meta);
         const size_t trow0 = ((size_t)gi * p.nblk + blk) * 16;                       // tangent rows of this block
@@ -269,7 +292,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
                 OP tein;
                 r16::load_set(u1, p.te + (trow0 + j) * F, q);
                 tein.set(u1);
-                const float* tprow = p.tP + (size_t)((gi * p.G + row_mol(meta)) * p.A + row_src(meta)) * F;
+                const float* tprow = p.tP + (size_t)((vmg * p.G + row_mol(meta)) * p.A + row_src(meta)) * F;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     const f32x4* wl = pipe.acquire();
@@ -309,15 +332,15 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
         // ---- output layer, flipped (features on lanes, the block's rows 4q + r in registers); see painn_edge_kernel
         uint32_t mi[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mi[r] = p.rows[blk * 16 + 4 * q + r];
+        for (int r = 0; r < 4; ++r) mi[r] = rows[blk * 16 + 4 * q + r];
         f32x4 sel;
         int snode[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             sel[r] = (row_slot(mi[r]) == j) ? 1.0f : 0.0f;
-            const int sn = p.slotnode[blk * 16 + 4 * q + r];
+            const int sn = slotnode[blk * 16 + 4 * q + r];
             const long long m2 = sn >> 8;
-            snode[r] = (sn >= 0 && group_ok && pg * p.G + m2 < p.B) ? (int)((gi * p.G + m2) * p.A + (sn & 255)) : -1;     // TANGENT node
+            snode[r] = (sn >= 0 && group_ok && mg * p.G + m2 < p.B) ? (int)((vmg * p.G + m2) * p.A + (sn & 255)) : -1;     // TANGENT node
         }
         f32x4 dir[4], tdir[4], dd;
 #pragma unroll
@@ -372,10 +395,10 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
                 if (!first) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        long long pm2 = pg * p.G + row_mol(mi[r]);
+                        long long pm2 = mg * p.G + row_mol(mi[r]);
                         pm2 = pm2 < p.B ? pm2 : p.B - 1;
                         const float* vp = p.v + (size_t)(pm2 * p.A + row_src(mi[r])) * 3 * F + fo;
-                        const float* tp = p.tv + (size_t)((gi * p.G + row_mol(mi[r])) * p.A + row_src(mi[r])) * 3 * F + fo;
+                        const float* tp = p.tv + (size_t)((vmg * p.G + row_mol(mi[r])) * p.A + row_src(mi[r])) * 3 * F + fo;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16];
@@ -416,6 +439,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
         }
         if (p.pad) { (void)pipe.acquire(); pipe.release(); }      // odd chunk count: swallow the pad chunk, stay in phase with the superchunk ring
     }
+    pipe.drain();
 }
 
 // ================================================================================================== primal node pass
@@ -601,13 +625,14 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_node_kernel(const JvpNodePar
         }
         park(10 + c, uv);
     }
+    pipe.drain();
 }
 
 // ================================================================================================== tangent update kernel
 // Runs BEFORE the primal update kernel of the same layer: reads the primal v and cacc as the edge kernel left them and the
 // primal node pass output, advances ts, tv, tP; the tangent accumulators are consumed and zeroed.  Tangent products only.
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kernel(const JvpUpdateParams p)
+__global__ __launch_bounds__(256, (NBK <= 8 ? TI_JVP_UPD_OCC : 1)) void painn_jvp_update_kernel(const JvpUpdateParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -801,12 +826,13 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kern
             if (ok) { r16::store_block(p.tP + (size_t)nd * F, 2 * ch, q, a0); r16::store_block(p.tP + (size_t)nd * F, 2 * ch + 1, q, a1); }
         }
     }
+    pipe.drain();
 }
 
 // ================================================================================================== tangent readout kernel
 // tout[vnode][c] = (Vr . tv_c) gate + (Vr . v_c) tgate   (LayerReadout.forward, cpainn.py:425-437)
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpReadoutParams p)
+__global__ __launch_bounds__(256, TI_JVP_RO_OCC) void painn_jvp_readout_kernel(const JvpReadoutParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -816,7 +842,17 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
     float* vec = reinterpret_cast<float*>(lds + 4 * CH4);
     for (int i = threadIdx.x; i < RV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    PipeDMA<NB, T, 2> pipe;
+#ifdef TI_JVP_RO_REGPIPE
+    struct {
+        Pipe<NB, T, 1> p;
+        __device__ __forceinline__ void init(const f32x4* s2, int n, f32x4* l, int, int) { p.init(s2, n, l); }
+        __device__ __forceinline__ const f32x4* acquire() { return p.begin(); }
+        __device__ __forceinline__ void release() { p.end(); }
+        __device__ __forceinline__ void drain() {}
+    } pipe;
+#else
+    PipeDMA<NB, T, TI_JVP_RO_SC> pipe;
+#endif
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
     const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;      // virtual node
@@ -840,12 +876,20 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = r16::load_block(vec + RV::B0 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B0 * F, 2 * ch + 1, q);
             f32x4 b0 = Z4, b1 = Z4;
+#ifdef TI_JVP_RO_UNPAIRED
+            r16::gemm_bt(a0, a1, ss, wl, lane); r16::gemm_bt(b0, b1, tss, wl, lane);
+#else
             r16::gemm_bt2(a0, a1, b0, b1, ss, tss, wl, lane);
+#endif
             t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
             pipe.release();
         }
     }
+#ifdef TI_JVP_RO_LNSPLIT
+    { A16 nn, kk; r16::ln_silu_stats(t, nn, kk, vec + RV::G0 * F, vec + RV::BE0 * F, q); r16::ln_tangent(u, nn, kk); }
+#else
     r16::ln_silu_dual(t, u, vec + RV::G0 * F, vec + RV::BE0 * F, q);
+#endif
     {
         OP h1, th1;
         h1.set(t); th1.set(u);
@@ -854,12 +898,20 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = r16::load_block(vec + RV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B1 * F, 2 * ch + 1, q);
             f32x4 b0 = Z4, b1 = Z4;
+#ifdef TI_JVP_RO_UNPAIRED
+            r16::gemm_bt(a0, a1, h1, wl, lane); r16::gemm_bt(b0, b1, th1, wl, lane);
+#else
             r16::gemm_bt2(a0, a1, b0, b1, h1, th1, wl, lane);
+#endif
             t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
             pipe.release();
         }
     }
+#ifdef TI_JVP_RO_LNSPLIT
+    { A16 nn, kk; r16::ln_silu_stats(t, nn, kk, vec + RV::G1 * F, vec + RV::BE1 * F, q); r16::ln_tangent(u, nn, kk); }
+#else
     r16::ln_silu_dual(t, u, vec + RV::G1 * F, vec + RV::BE1 * F, q);
+#endif
     float gate = 0.f, tgate = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
@@ -872,6 +924,9 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float acc = 0.f, tacc = 0.f;
+#ifdef TI_JVP_RO_FENCE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) {
             const f32x4 w = r16::load_block(vec + RV::VR * F, nb, q);
@@ -879,9 +934,16 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_readout_kernel(const JvpRead
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc = fmaf(vv[r], w[r], acc); tacc = fmaf(tv[r], w[r], tacc); }
         }
+#ifdef TI_JVP_RO_FENCE2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         acc = r16::xquarters(acc); tacc = r16::xquarters(tacc);
+#ifdef TI_JVP_RO_FENCE2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         if (ok && q == 0) p.tout[nd * 3 + c] = tacc * gate + acc * tgate;
     }
+    pipe.drain();
 }
 
 // div[b] = sum_d tangent[(virtual molecule of (b, d))][d]  (unit seeds: direction d = 3 atom + component is also the flat
@@ -898,7 +960,16 @@ __global__ void painn_div_reduce_kernel(const float* __restrict__ tout, long lon
 
 // ================================================================================================== launchers
 static size_t jvp_edge_lds(int NB) { return 4 * (size_t)256 * NB * 16 + 4 * 128 * 4 + EV::COUNT * (size_t)32 * NB * 4; }
-static size_t jvp_node_lds(int NB, int count) { return 4 * (size_t)256 * NB * 16 + (size_t)count * 32 * NB * 4; }
+static size_t jvp_node_lds(int NB, int count)
+{
+#ifdef TI_JVP_RO_BIGLDS
+    if (count == RV::COUNT) return 100 * 1024;
+#endif
+#ifdef TI_JVP_RO_PADLDS
+    if (count == RV::COUNT) return 4 * (size_t)256 * NB * 16 + (size_t)count * 32 * NB * 4 + TI_JVP_RO_PADLDS;
+#endif
+    return 4 * (size_t)256 * NB * 16 + (size_t)count * 32 * NB * 4;
+}
 
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes)

@@ -138,11 +138,15 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
+    // a group is P "parts" (ranges of destination atoms, each with its own row blocks and its own wave): ti_internal.hpp
+    const long long mg = gi / p.parts;
+    const uint32_t* rows = p.rows + (size_t)(gi - mg * p.parts) * p.nblk * 16;
+    const int32_t* slotnode = p.slotnode + (size_t)(gi - mg * p.parts) * p.nblk * 16;
 
     for (int blk = 0; blk < p.nblk; ++blk) {
         // ---- K1 geometry of this lane's row (the 4 quarters compute the same row)
-        const uint32_t meta = p.rows[blk * 16 + j];
-        long long mol = gi * p.G + row_mol(meta);
+        const uint32_t meta = rows[blk * 16 + j];
+        long long mol = mg * p.G + row_mol(meta);
         mol = mol < p.B ? mol : p.B - 1;
         const long long nsrc = mol * p.A + row_src(meta), ndst = mol * p.A + row_dst(meta);
         const size_t erow0 = ((size_t)gi * p.nblk + blk) * 16;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
         // ---- output layer, flipped: features on lanes (l & 15), the block's rows 4q + r in registers
         uint32_t mi[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mi[r] = p.rows[blk * 16 + 4 * q + r];
+        for (int r = 0; r < 4; ++r) mi[r] = rows[blk * 16 + 4 * q + r];
         // Per-atom sums over the block's rows as a 16x16 selection product on the matrix core:
         //   S[slot][n] = sum_row Sel[slot][row] * val[row][n],  Sel[slot][row] = 1 if the row's destination is that slot.
         // val is already in B-operand layout (lane (n, q) holds rows 4q + r); Sel in A-operand layout is sel[r] below.  The
@@ -236,8 +240,8 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             sel[r] = (row_slot(mi[r]) == j) ? 1.0f : 0.0f;
-            const int sn = p.slotnode[blk * 16 + 4 * q + r];
-            const long long m2 = gi * p.G + (sn >> 8);
+            const int sn = slotnode[blk * 16 + 4 * q + r];
+            const long long m2 = mg * p.G + (sn >> 8);
             snode[r] = (sn >= 0 && group_ok && m2 < p.B) ? (int)(m2 * p.A + (sn & 255)) : -1;
         }
 
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
                 if (!FIRST) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        long long m2 = gi * p.G + row_mol(mi[r]);
+                        long long m2 = mg * p.G + row_mol(mi[r]);
                         m2 = m2 < p.B ? m2 : p.B - 1;
                         const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
 #pragma unroll
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_
             }
         }
     }
+    pipe.drain();
 }
 
 // ================================================================================================== update kernel
@@ -533,6 +538,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             if (ok) { r16::store_block(p.P + nd * F, 2 * ch, q, a0); r16::store_block(p.P + nd * F, 2 * ch + 1, q, a1); }
         }
     }
+    pipe.drain();
 }
 
 // ================================================================================================== readout kernel

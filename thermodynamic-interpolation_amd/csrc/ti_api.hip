@@ -117,7 +117,16 @@ struct ti_handle {
     MlpOff embed{}, readout{}; std::vector<MlpOff> phi, w, upd; std::vector<size_t> U, V;
     size_t edge_emb = 0, atom_emb = 0, Vr = 0; float b2_gate = 0.f;
     Stream st_embed{}, st_readout{}; std::vector<Stream> st_edge, st_update;
-    DevBuf<uint32_t> rows; DevBuf<int32_t> slotnode, nslots, atom_ids;
+    // edge templates (ti_internal.hpp): [0] throughput (G molecules per group), [1] latency (G = 1, P parts per molecule);
+    // G / P / nblk / rows / slotnode below are those of the ACTIVE one (select_template, once per API call)
+    struct Tpl {
+        int G = 1, P = 1, nblk = 0;
+        DevBuf<uint32_t> rows; DevBuf<int32_t> slotnode;
+        std::vector<int> part_of, part_start;     // per sorted edge: its part; per part: first sorted edge
+    } tpl[2];
+    int n_tpl = 1, active = 0, parts = 1;
+    struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
+    DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
     DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs, upd_vecs;
     int tap = -1; long long last_B = 0;
@@ -166,45 +175,124 @@ struct Timed {           // RAII: brackets a launch with HIP events when profili
 void set_device(const ti_handle* h) { HIP_CHECK(hipSetDevice(h->device)); }
 
 // ------------------------------------------------------------------------------------------------ painn create
-void build_template(ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype)
+// rows of `count` molecules' edges whose destination atom lies in [a0, a1), padded to whole 16-row blocks
+static void fill_part(const ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype, int count, int k0, int k1, int nblk,
+                      uint32_t* rw, int32_t* sn)
 {
-    const int A = h->d.n_atoms, E = h->d.n_edges;
-    h->perm.resize(E);
-    for (int k = 0; k < E; ++k) h->perm[k] = k;
-    std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) {
-        return dst[a] != dst[b] ? dst[a] < dst[b] : src[a] < src[b];
-    });
-    // the edge kernel walks a group in blocks of RB = 16 rows
-    // group size: smallest G in 1..8 whose padding waste is <= 2 %, else the least wasteful
     constexpr int RB = ti::EDGE_ROWS_PER_BLOCK;
-    int bestG = 1; double bestW = 2.0;
-    for (int G = 1; G <= 8 && E > 0; ++G) {
-        const int rows = G * E, padded = (rows + RB - 1) / RB * RB;
-        const double waste = double(padded - rows) / padded;
-        if (waste < bestW - 1e-12) { bestW = waste; bestG = G; }
-        if (waste <= 0.02) { bestG = G; break; }
-    }
-    if (const char* fg = std::getenv("TI_FORCE_G")) bestG = std::max(1, std::min(8, std::atoi(fg)));      // experiments only
-    h->G = bestG;
-    const int rows = h->G * E;
-    h->nblk = (rows + RB - 1) / RB;
-    std::vector<uint32_t> rw((size_t)std::max(h->nblk, 1) * RB, (uint32_t)63 << 18);
-    std::vector<int32_t> sn((size_t)std::max(h->nblk, 1) * RB, -1), ns(std::max(h->nblk, 1), 0);
-    for (int blk = 0; blk < h->nblk; ++blk) {
+    const int per = k1 - k0, rows = count * per;
+    for (int i = 0; i < nblk * RB; ++i) { rw[i] = (uint32_t)63 << 18; sn[i] = -1; }
+    for (int blk = 0; blk < nblk; ++blk) {
         int nslot = 0, last_key = -1;
         for (int j = 0; j < RB; ++j) {
             const int r = blk * RB + j;
             if (r >= rows) break;
-            const int m = r / E, k = h->perm[r % E];
+            const int m = r / per, k = h->perm[k0 + r % per];
             const int key = m * 256 + dst[k];
             if (key != last_key) { sn[(size_t)blk * RB + nslot] = (m << 8) | dst[k]; ++nslot; last_key = key; }
             rw[r] = 1u | ((uint32_t)m << 1) | ((uint32_t)src[k] << 6) | ((uint32_t)dst[k] << 11) | ((uint32_t)etype[k] << 16) |
                     ((uint32_t)(nslot - 1) << 18);
         }
-        ns[blk] = nslot;
     }
-    (void)A;
-    h->rows.upload(rw); h->slotnode.upload(sn); h->nslots.upload(ns);
+}
+
+void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype)
+{
+    const int A = h->d.n_atoms, E = h->d.n_edges;
+    constexpr int RB = ti::EDGE_ROWS_PER_BLOCK;
+    h->perm.resize(E);
+    for (int k = 0; k < E; ++k) h->perm[k] = k;
+    std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) {
+        return dst[a] != dst[b] ? dst[a] < dst[b] : src[a] < src[b];
+    });
+    // ---- throughput template: smallest G in 1..8 whose padding waste is <= 2 %, else the least wasteful
+    {
+        int bestG = 1; double bestW = 2.0;
+        for (int G = 1; G <= 8 && E > 0; ++G) {
+            const int rows = G * E, padded = (rows + RB - 1) / RB * RB;
+            const double waste = double(padded - rows) / padded;
+            if (waste < bestW - 1e-12) { bestW = waste; bestG = G; }
+            if (waste <= 0.02) { bestG = G; break; }
+        }
+        if (const char* fg = std::getenv("TI_FORCE_G")) bestG = std::max(1, std::min(8, std::atoi(fg)));      // experiments only
+        ti_handle::Tpl& T = h->tpl[0];
+        T.G = bestG; T.P = 1; T.nblk = (bestG * E + RB - 1) / RB;
+        T.part_of.assign(E, 0); T.part_start.assign(1, 0);
+        std::vector<uint32_t> rw((size_t)std::max(T.nblk, 1) * RB); std::vector<int32_t> sn(rw.size());
+        fill_part(h, src, dst, etype, bestG, 0, E, T.nblk, rw.data(), sn.data());
+        if (T.nblk == 0) { rw[0] = (uint32_t)63 << 18; sn[0] = -1; }
+        T.rows.upload(rw); T.slotnode.upload(sn);
+    }
+    // ---- latency template: one molecule per group, its destination atoms cut into P ranges of near-equal row count; the
+    // largest P <= 8 whose padding waste stays <= 15 % (parts need whole row blocks).  Built only if it offers more waves.
+    h->n_tpl = 1;
+    if (E >= 2 * RB) {
+        std::vector<int> first_of(A + 1, E);           // first sorted edge with destination >= a
+        for (int k = E - 1; k >= 0; --k) first_of[dst[h->perm[k]]] = k;
+        for (int a = A - 1; a >= 0; --a) first_of[a] = std::min(first_of[a], first_of[a + 1]);
+        int bestP = 1, best_nblk = (E + RB - 1) / RB; std::vector<int> best_cut{0, E};
+        for (int P = 2; P <= 8; ++P) {
+            std::vector<int> cut{0};
+            for (int q = 1; q < P; ++q) {             // atom boundary closest to q/P of the rows
+                const int want = (int)((long long)E * q / P);
+                int bk = cut.back();
+                for (int a = 0; a <= A; ++a) if (first_of[a] > cut.back() && std::abs(first_of[a] - want) < std::abs(bk - want)) bk = first_of[a];
+                if (bk <= cut.back()) { cut.clear(); break; }
+                cut.push_back(bk);
+            }
+            if (cut.empty() || cut.back() >= E) continue;
+            cut.push_back(E);
+            int nblk = 0;
+            for (int q = 0; q < P; ++q) nblk = std::max(nblk, (cut[q + 1] - cut[q] + RB - 1) / RB);
+            if (double(P * nblk * RB - E) / (P * nblk * RB) <= 0.15) { bestP = P; best_nblk = nblk; best_cut = cut; }
+        }
+        if (bestP * h->tpl[0].G > 1) {
+            ti_handle::Tpl& T = h->tpl[1];
+            T.G = 1; T.P = bestP; T.nblk = best_nblk;
+            T.part_start.assign(best_cut.begin(), best_cut.end() - 1);
+            T.part_of.resize(E);
+            for (int q = 0; q < bestP; ++q) for (int k = best_cut[q]; k < best_cut[q + 1]; ++k) T.part_of[k] = q;
+            std::vector<uint32_t> rw((size_t)bestP * best_nblk * RB); std::vector<int32_t> sn(rw.size());
+            for (int q = 0; q < bestP; ++q)
+                fill_part(h, src, dst, etype, 1, best_cut[q], best_cut[q + 1], best_nblk, rw.data() + (size_t)q * best_nblk * RB,
+                          sn.data() + (size_t)q * best_nblk * RB);
+            T.rows.upload(rw); T.slotnode.upload(sn);
+            h->n_tpl = 2;
+        }
+    }
+}
+
+// Template for a call over B molecules: the latency template while the throughput one would leave SIMDs without a wave
+// (fewer groups than the 1024 SIMDs of the chip); TI_TEMPLATE=throughput|latency pins it (tests, reproducibility across shards).
+void select_template(ti_handle* h, long long B)
+{
+    int pick = 0;
+    if (h->n_tpl > 1) {
+        const long long groups0 = (B + h->tpl[0].G - 1) / h->tpl[0].G;
+        pick = groups0 < 1024 ? 1 : 0;
+        if (const char* e = std::getenv("TI_TEMPLATE")) pick = std::strcmp(e, "latency") == 0 ? 1 : std::strcmp(e, "throughput") == 0 ? 0 : pick;
+    }
+    const ti_handle::Tpl& T = h->tpl[pick];
+    h->active = pick; h->G = T.G; h->parts = T.P; h->nblk = T.nblk; h->rows.p = T.rows.p; h->slotnode.p = T.slotnode.p;
+}
+
+// row of (molecule m, sorted edge k) in the e / te layout of the active template
+size_t edge_row_of(const ti_handle* h, size_t m, size_t k)
+{
+    const ti_handle::Tpl& T = h->tpl[h->active];
+    const size_t part = T.part_of[k], r = (m % T.G) * (T.P == 1 ? (size_t)h->d.n_edges : 0) + (k - T.part_start[part]);
+    return ((m / T.G) * T.P + part) * T.nblk * ti::EDGE_ROWS_PER_BLOCK + r;
+}
+
+// edge rows (e, te) per molecule-group slot, the larger of the two templates: rows a batch of B molecules needs
+size_t edge_rows_for(const ti_handle* h, long long B, long long copies = 1)
+{
+    size_t best = 1;
+    for (int t = 0; t < h->n_tpl; ++t) {
+        const ti_handle::Tpl& T = h->tpl[t];
+        best = std::max<size_t>(best, (size_t)((B + T.G - 1) / T.G) * (size_t)copies * T.P * T.nblk * ti::EDGE_ROWS_PER_BLOCK);
+    }
+    return best;
 }
 
 void pack_painn(ti_handle* h, const float* wts)
@@ -289,8 +377,13 @@ void pack_painn(ti_handle* h, const float* wts)
     o = begin_stream();
     layer(h->readout.W0, F, F, 0); layer(h->readout.W1, F, F, 0);
     h->st_readout = end_stream(o);
-    o = begin_stream();                              // tangent readout kernel: 16-row chunk format
-    layer16(h->readout.W0, F, F, 0); layer16(h->readout.W1, F, F, 0);
+    // tangent readout kernel: 16-row chunk format, always f32 operands.  Its split-fp16 build returned sporadically wrong
+    // (Vr . v) sums for whole 16-node tiles whenever two of its workgroups shared a CU (1 tile in ~2 000; never with one
+    // workgroup per CU, never in the f32 build; LDS-DMA, barriers and waits were ruled out -- DESIGN.md 3.5); the kernel is
+    // 0.5 % of a divergence evaluation, so it simply stays on the f32 path.
+    o = begin_stream();
+    for (size_t Wm : {h->readout.W0, h->readout.W1})
+        for (int nbo = 0; nbo < NB; ++nbo) pack_chunk16(pk, wts + Wm, F, F, 32 * nbo, 0, NBK);
     pad_even(o);
     h->st_jvp_readout = end_stream(o);
     h->packed.upload(pk);
@@ -325,12 +418,11 @@ void ensure_painn_ws(ti_handle* h, long long B)
 {
     if (B <= h->cap) return;
     const size_t A = h->d.n_atoms, F = h->d.n_features, N = (size_t)B * A;
-    const size_t groups = ((size_t)B + h->G - 1) / h->G;
     h->x.alloc(N * 3); h->b1.alloc(N * 3); h->b2.alloc(N * 3); h->xt.alloc(N * 3);
     h->cond.alloc(std::max<size_t>(N * h->ncond, 1));
     h->s.alloc(N * F); h->P.alloc(N * F);
     h->v.alloc(N * 3 * F); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F); h->dsacc.alloc(N * F);
-    h->e.alloc(std::max<size_t>(groups * h->nblk * ti::EDGE_ROWS_PER_BLOCK * F, 1));
+    h->e.alloc(edge_rows_for(h, B) * F);
     h->divb.alloc(B); h->div2.alloc(B); h->dl.alloc(B); h->dlscaled.alloc(B);
     h->cap = B;
 }
@@ -341,7 +433,7 @@ long long jvp_virtual_molecules(const ti_handle* h, long long B, int D) { return
 size_t jvp_bytes_per_vm(const ti_handle* h)
 {
     const size_t A = h->d.n_atoms, F = h->d.n_features;
-    const size_t erows = ((size_t)h->nblk * ti::EDGE_ROWS_PER_BLOCK + h->G - 1) / h->G;
+    const size_t erows = ((size_t)h->parts * h->nblk * ti::EDGE_ROWS_PER_BLOCK + h->G - 1) / h->G;
     return (A * F * 12 + erows * F + A * 3) * sizeof(float);
 }
 
@@ -349,19 +441,19 @@ void ensure_jvp_ws(ti_handle* h, long long B, int D)
 {
     const long long VB = jvp_virtual_molecules(h, B, D);
     const size_t A = h->d.n_atoms, F = h->d.n_features, N = (size_t)VB * A;
-    const size_t pgroups = ((size_t)B + h->G - 1) / h->G;
+    const size_t pgroups = ((size_t)B + h->G - 1) / h->G * h->parts;
     const size_t wq_floats = std::max<size_t>(pgroups * h->nblk * 5 * h->NB * 6 * 64 * 4, 4);
     const size_t st_floats = std::max<size_t>(pgroups * h->nblk * 4 * (2 * h->NB) * 64 * 4, 4);
     if (h->wq.n < wq_floats) h->wq.alloc(wq_floats);
     if (h->phist.n < st_floats) h->phist.alloc(st_floats);
     const size_t ns_floats = (((size_t)B * A + 15) / 16) * 13 * (2 * h->NB) * 64 * 4;
     if (h->nodest.n < ns_floats) h->nodest.alloc(ns_floats);
+    const size_t te_floats = (size_t)VB / h->G * h->parts * h->nblk * ti::EDGE_ROWS_PER_BLOCK * F;
+    if (h->te.n < te_floats) h->te.alloc(std::max<size_t>(te_floats, 1));
     if (VB <= h->jvp_cap) return;
     if (N >= ((size_t)1 << 31)) throw std::invalid_argument("too many tangent nodes in one pass (lower TI_JVP_WS_GB)");
-    const size_t groups = (size_t)VB / h->G;
     h->ts.alloc(N * F); h->tP.alloc(N * F); h->tdsacc.alloc(N * F);
     h->tv.alloc(N * 3 * F); h->tdvacc.alloc(N * 3 * F); h->tcacc.alloc(N * 3 * F);
-    h->te.alloc(std::max<size_t>(groups * h->nblk * ti::EDGE_ROWS_PER_BLOCK * F, 1));
     h->tout.alloc(N * 3);
     h->jvp_cap = VB;
 }
@@ -390,10 +482,10 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
                      const JvpRun* jr = nullptr)
 {
     const int A = h->d.n_atoms, F = h->d.n_features, L = h->d.n_layers, NB = h->NB;
-    const long long N = B * A, groups = (B + h->G - 1) / h->G;
+    const long long N = B * A, groups = (B + h->G - 1) / h->G * h->parts;         // edge-kernel waves: (molecule group, part)
     hipStream_t st = h->stream;
     const bool split = h->d.precision == TI_PREC_F16X2;
-    const long long VB = jr ? jvp_virtual_molecules(h, B, jr->D) : 0, VN = VB * A, vgroups = VB / h->G;
+    const long long VB = jr ? jvp_virtual_molecules(h, B, jr->D) : 0, VN = VB * A, vgroups = VB / h->G * h->parts;
     if (jr) {
         ensure_jvp_ws(h, B, jr->D);
         h->last_VB = B * jr->D; h->last_D = jr->D;
@@ -425,7 +517,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             {
                 JvpFilterParams p{};
                 p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
-                p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.nblk = h->nblk; p.G = h->G; p.A = A; p.first = l == 0; p.last = l == L - 1;
+                p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.first = l == 0; p.last = l == L - 1;
                 p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale; p.x = x_dev; p.P = h->P.p; p.e = h->e.p;
                 p.wq = reinterpret_cast<float4*>(h->wq.p); p.st = reinterpret_cast<float4*>(h->phist.p);
                 Timed tm(h, TI_KERNEL_PAINN_JVP_FILTER);
@@ -434,7 +526,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             JvpEdgeParams p{};
             p.stream = h->S(h->st_jvp_phi[l]); p.nch = h->st_jvp_phi[l].nch; p.pad = h->jvp_phi_pad[l]; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
             p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p;
-            p.nblk = h->nblk; p.G = h->G; p.A = A; p.D = jr->D; p.first = l == 0; p.last = l == L - 1;
+            p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.D = jr->D; p.first = l == 0; p.last = l == L - 1;
             p.B = B; p.n_groups = vgroups;
             p.x = x_dev; p.xdot = jr->xdot; p.P = h->P.p; p.v = h->v.p; p.e = h->e.p; p.wq = reinterpret_cast<const float4*>(h->wq.p);
             p.st = reinterpret_cast<const float4*>(h->phist.p); p.tP = h->tP.p; p.tv = h->tv.p;
@@ -445,8 +537,8 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         if (h->nblk > 0) {
             EdgeParams p{};
             p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
-            p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p; p.nslots = h->nslots.p;
-            p.nblk = h->nblk; p.G = h->G; p.A = A; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
+            p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p; p.nslots = nullptr;
+            p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
             p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
             HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, h->d.precision == TI_PREC_F16X2, p, st));
@@ -483,7 +575,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         p.stream = h->S(h->st_jvp_readout); p.nch = h->st_jvp_readout.nch; p.vecs = h->jvp_ro_vecs.p; p.b2_gate = h->b2_gate;
         p.N = VN; p.B = B; p.A = A; p.D = jr->D; p.G = h->G; p.s = h->s.p; p.v = h->v.p; p.ts = h->ts.p; p.tv = h->tv.p; p.tout = jr->tout;
         Timed tm(h, TI_KERNEL_PAINN_JVP_READOUT);
-        HIP_CHECK(launch_jvp_readout(NB, split, p, st));
+        HIP_CHECK(launch_jvp_readout(NB, false, p, st));        // f32 operands always (see pack_painn)
     }
     {
         ReadoutParams p{};
@@ -889,7 +981,8 @@ ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t 
         h->Vr = vr_aligned;
         h->flat.upload(flat);
         h->atom_ids.upload(std::vector<int32_t>(atom_ids, atom_ids + A));
-        build_template(h.get(), edge_src, edge_dst, edge_type);
+        build_templates(h.get(), edge_src, edge_dst, edge_type);
+        select_template(h.get(), 1 << 20);
         pack_painn(h.get(), weights);
         HIP_CHECK(configure_painn_kernels(h->NB));
         HIP_CHECK(configure_painn_jvp_kernels(h->NB));
@@ -912,6 +1005,7 @@ int ti_painn_drift(ti_handle* h, const float* x, float t, const float* cond, int
     if (B == 0) return TI_OK;
     return guarded([&]() -> int {
         set_device(h);
+        select_template(h, B);
         ensure_painn_ws(h, B);
         const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
         const float *xd = x, *cd = cond; float* od = out;
@@ -936,6 +1030,7 @@ int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* rd, const float* x0, c
     if (B == 0) { if (n_fevals) *n_fevals = 0; return TI_OK; }
     return guarded([&]() -> int {
         set_device(h);
+        select_template(h, B);
         ensure_painn_ws(h, B);
         const int A = h->d.n_atoms;
         const size_t n = (size_t)B * A * 3, nc = (size_t)B * A * h->ncond;
@@ -960,6 +1055,7 @@ int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t,
     if (B == 0) return TI_OK;
     return guarded([&]() -> int {
         set_device(h);
+        select_template(h, B);
         ensure_painn_ws(h, B);
         ensure_jvp_ws(h, B, 1);
         const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
@@ -989,6 +1085,7 @@ int ti_painn_drift_div(ti_handle* h, const float* x, float t, const float* cond,
     if (h->tap >= 0) return fail(TI_E_ARG, "debug taps apply to ti_painn_drift / ti_painn_drift_jvp only");
     return guarded([&]() -> int {
         set_device(h);
+        select_template(h, B);
         ensure_painn_ws(h, B);
         const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
         const float *xd = x, *cd = cond; float *od = out, *dd = out_div;
@@ -1017,6 +1114,7 @@ int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* rd, const float*
     if (B == 0) { if (n_fevals) *n_fevals = 0; return TI_OK; }
     return guarded([&]() -> int {
         set_device(h);
+        select_template(h, B);
         ensure_painn_ws(h, B);
         const int A = h->d.n_atoms;
         const size_t n = (size_t)B * A * 3, nc = (size_t)B * A * h->ncond;
@@ -1078,14 +1176,12 @@ int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)
                     }
         } else if (what == 2) {
             if (n_floats != B * E * F) return fail(TI_E_ARG, "size mismatch (e)");
-            const size_t RB = ti::EDGE_ROWS_PER_BLOCK, groups = (B + h->G - 1) / h->G, rows = groups * h->nblk * RB;
+            const size_t RB = ti::EDGE_ROWS_PER_BLOCK, rows = (B + h->G - 1) / h->G * h->parts * h->nblk * RB;
             std::vector<float> e(rows * F);
             HIP_CHECK(hipMemcpy(e.data(), h->e.p, e.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (size_t m = 0; m < B; ++m)
-                for (size_t k = 0; k < E; ++k) {
-                    const size_t gi = m / h->G, r = (m % h->G) * E + k;          // k = sorted position
-                    std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + (gi * h->nblk * RB + r) * F, F * sizeof(float));
-                }
+                for (size_t k = 0; k < E; ++k)                                   // k = sorted position
+                    std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + edge_row_of(h, m, k) * F, F * sizeof(float));
         } else if (what >= 3 && what <= 5) {
             // tangents of the last ti_painn_drift_jvp call (one direction per molecule), composed like their primal twins
             if (h->last_D != 1 || (size_t)h->last_VB != B) return fail(TI_E_ARG, "tangent taps need a preceding ti_painn_drift_jvp call");
@@ -1108,13 +1204,11 @@ int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)
                         }
             } else {
                 if (n_floats != B * E * F) return fail(TI_E_ARG, "size mismatch (te)");
-                const size_t RB = ti::EDGE_ROWS_PER_BLOCK, groups = (B + h->G - 1) / h->G, rows = groups * h->nblk * RB;
+                const size_t RB = ti::EDGE_ROWS_PER_BLOCK, rows = (B + h->G - 1) / h->G * h->parts * h->nblk * RB;
                 const auto e = fetch(h->te, rows * F);
                 for (size_t m = 0; m < B; ++m)
-                    for (size_t k = 0; k < E; ++k) {
-                        const size_t gi = m / h->G, r = (m % h->G) * E + k;
-                        std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + (gi * h->nblk * RB + r) * F, F * sizeof(float));
-                    }
+                    for (size_t k = 0; k < E; ++k)
+                        std::memcpy(out + (m * E + h->perm[k]) * F, e.data() + edge_row_of(h, m, k) * F, F * sizeof(float));
             }
         } else return fail(TI_E_ARG, "unknown tap");
         return TI_OK;

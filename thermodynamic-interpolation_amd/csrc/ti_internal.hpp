@@ -12,6 +12,10 @@
 namespace ti {
 
 // ---- molecule-group edge template -------------------------------------------------------------------------------
+// Two templates are built per handle (ti_api.hip: build_templates): "throughput" (G molecules per group, P = 1: fewest padded
+// rows, one wave walks G*E_m rows) and "latency" (G = 1, the destination atoms of a molecule cut into P parts, each part padded
+// to whole row blocks and walked by its own wave: P times the waves for small batches).  A kernel's group index counts
+// (molecule group, part):  gi = mg * parts + part;  rows / slotnode hold [parts][nblk*16] entries.
 // The E_m edges of one molecule are sorted by (dst, src); G molecules form a "group" whose G*E_m edge rows are padded
 // to NBLK blocks of EDGE_ROWS_PER_BLOCK rows.  One wave owns one group, so every per-atom sum over incoming edges stays inside a wave
 // in that wave's program order (deterministic).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots".
@@ -34,7 +38,7 @@ struct EdgeParams {
     const float* vecs;                      // [21][F] bias/gamma/beta of the w and phi MLPs (painn_kernels.hip: struct EV)
     const float* edge_emb;                  // [4][F]  (first layer: e = edge_emb[type])
     const uint32_t* rows; const int32_t* slotnode; const int32_t* nslots;
-    int nblk, G, A;
+    int nblk, G, parts, A;                  // parts per group (see above); n_groups counts parts
     long long B, n_groups;
     float length_scale;
     const float* x;                         // [B*A][3]
@@ -82,8 +86,8 @@ hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
 struct JvpFilterParams {                    // primal pass of one layer's message block (painn_jvp_filter_kernel)
     const float4* stream; int nch; const float* vecs; const float* edge_emb;      // the primal edge stream / vector block
     const uint32_t* rows;
-    int nblk, G, A, first, last;
-    long long B, n_groups;                  // molecules, primal groups
+    int nblk, G, parts, A, first, last;
+    long long B, n_groups;                  // molecules, primal groups (incl. parts)
     float length_scale;
     const float *x, *P, *e;
     float4* wq;                             // [n_groups*nblk][5][NB][6][64] float4: phi_o, w_o, d w_o / d|r|
@@ -92,8 +96,8 @@ struct JvpFilterParams {                    // primal pass of one layer's messag
 struct JvpEdgeParams {
     const float4* stream; int nch, pad; const float* vecs; const float* edge_emb;
     const uint32_t* rows; const int32_t* slotnode;
-    int nblk, G, A, D, first, last;
-    long long B, n_groups;                  // molecules, VIRTUAL groups (= primal groups * D)
+    int nblk, G, parts, A, D, first, last;
+    long long B, n_groups;                  // molecules, VIRTUAL groups (= molecule groups * D * P)
     const float *x, *xdot;
     const float *P, *v, *e;                 // primal state entering this layer's message block
     const float4 *wq, *st;                  // primal pass output of this layer
