@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="adw,latent,a9,a25,f256,div")
+    ap.add_argument("--which", default="adw,latent,a9,a25,f256,div,dopri5")
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
     import torch
@@ -88,6 +88,28 @@ def main():
                    "cost_ratio_vs_plain_drift": dt_div / dt_b,
                    "kernel_ms": {k: round(v[1], 3) for k, v in prof.items()}, "kernel_launches": {k: v[0] for k, v in prof.items()}}
             print(json.dumps(rec))
+            eng.close()
+
+    if "dopri5" in which:
+        # the reference's default solver on the headline batch: adaptive Dormand-Prince, rtol = atol = 1e-4 (shipped configs),
+        # one shared step size per batch like torchdiffeq; reports evaluations taken and wall time for t = 0 -> 1
+        F, L, A, B = 128, 5, 18, 65536
+        src, dst, et = syn.fully_connected_template(A)
+        flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, 0), W.painn_param_spec(0, F, L, 25))
+        x0 = torch.from_numpy(syn.molecule_coords(B, A, 0)).to(dev)
+        cond = torch.from_numpy(syn.ambient_cond(B, A)).to(dev)
+        grid = ti.engine.time_grid(0.0, 1.0, 100)
+        out = torch.empty((1, B, A, 3), device=dev)
+        for prec in ("f16x2", "f32"):
+            eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision=prec)
+            eng.rollout(x0, cond, grid, scheme="dopri5", rtol=1e-4, atol=1e-4, save_every=0, out=out)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, nfe = eng.rollout(x0, cond, grid, scheme="dopri5", rtol=1e-4, atol=1e-4, save_every=0, out=out)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(json.dumps({"workload": "ambient dopri5 rollout t=0..1 (100-point output grid), 65536 molecules x 18 atoms, F=128 L=5, rtol=atol=1e-4",
+                              "precision": prec, "seconds": dt, "drift_evaluations": nfe, "molecule_evals_per_s": B * nfe / dt}))
             eng.close()
 
     for prec in ("f16x2", "f32"):
