@@ -26,6 +26,9 @@
  *     the handle's device (e.g. torch.Tensor.data_ptr()); device work is enqueued on the handle's stream and the
  *     call returns after that stream has been synchronised.
  *   - There is no CPU fallback: if no gfx950 device is usable, create() fails with TI_E_HIP.
+ *   - Environment (read per call): TI_TEMPLATE=throughput|latency pins the edge-row layout that is otherwise chosen from the
+ *     batch size (results agree to fp32 round-off; bit-identical within one layout); TI_JVP_WS_GB = HBM budget in GB for the
+ *     tangent state of the divergence (default 48).
  *
  * Weight layout ("canonical flat layout", fp32 unless noted; every tensor row-major in torch's [out, in] order)
  *   MLP(f_in, f_h, f_out) := W0[f_h,f_in] b0[f_h] g0[f_h] be0[f_h]  W1[f_h,f_h] b1[f_h] g1[f_h] be1[f_h]  W2[f_out,f_h] b2[f_out]

@@ -125,6 +125,7 @@ struct ti_handle {
         std::vector<int> part_of, part_start;     // per sorted edge: its part; per part: first sorted edge
     } tpl[2];
     int n_tpl = 1, active = 0, parts = 1;
+    bool jvp_ro_split = false;
     struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
     DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
@@ -382,8 +383,12 @@ void pack_painn(ti_handle* h, const float* wts)
     // workgroup per CU, never in the f32 build; LDS-DMA, barriers and waits were ruled out -- DESIGN.md 3.5); the kernel is
     // 0.5 % of a divergence evaluation, so it simply stays on the f32 path.
     o = begin_stream();
+    h->jvp_ro_split = split && std::getenv("TI_JVP_RO_SPLIT") != nullptr;          // diagnosis only (tools/diag_race.py)
     for (size_t Wm : {h->readout.W0, h->readout.W1})
-        for (int nbo = 0; nbo < NB; ++nbo) pack_chunk16(pk, wts + Wm, F, F, 32 * nbo, 0, NBK);
+        for (int nbo = 0; nbo < NB; ++nbo) {
+            if (h->jvp_ro_split) pack_chunk16_split(pk, wts + Wm, F, F, 32 * nbo, 0, NBK);
+            else pack_chunk16(pk, wts + Wm, F, F, 32 * nbo, 0, NBK);
+        }
     pad_even(o);
     h->st_jvp_readout = end_stream(o);
     h->packed.upload(pk);
@@ -575,7 +580,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         p.stream = h->S(h->st_jvp_readout); p.nch = h->st_jvp_readout.nch; p.vecs = h->jvp_ro_vecs.p; p.b2_gate = h->b2_gate;
         p.N = VN; p.B = B; p.A = A; p.D = jr->D; p.G = h->G; p.s = h->s.p; p.v = h->v.p; p.ts = h->ts.p; p.tv = h->tv.p; p.tout = jr->tout;
         Timed tm(h, TI_KERNEL_PAINN_JVP_READOUT);
-        HIP_CHECK(launch_jvp_readout(NB, false, p, st));        // f32 operands always (see pack_painn)
+        HIP_CHECK(launch_jvp_readout(NB, h->jvp_ro_split, p, st));        // f32 operands unless TI_JVP_RO_SPLIT (see pack_painn)
     }
     {
         ReadoutParams p{};

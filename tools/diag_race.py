@@ -78,3 +78,33 @@ for rep in range(6):
             sol, res, *_ = np.linalg.lstsq(M, e, rcond=None)
             print(f"   rep {rep} row {r} atom {a}: err {e}  -> dgate {sol[0]:.3e} dtgate {sol[1]:.3e} residual {np.abs(M @ sol - e).max():.1e}", flush=True)
             break
+
+
+# ---- stale-input hypotheses for the bad tiles: was (Vr . v) formed from the v of BEFORE the last update kernel, or (Vr . tv)
+# from the tv of before the last tangent update?
+print("---- stale-input hypotheses", flush=True)
+eng.debug_tap(2 * L - 2 if L > 1 else 0)          # state after the previous layer's update
+eng.jvp(x, xdot, 0.5, cond)
+v_prev = eng.debug_read("v", B).transpose(0, 1, 3, 2).astype(np.float64); tv_prev = eng.debug_read("tv", B).transpose(0, 1, 3, 2).astype(np.float64)
+eng.debug_tap(-1)
+ob, _ = orc.jvp(x, xdot, 0.5, cond, precision=64)
+for rep in range(6):
+    b, tan = eng.jvp(x, xdot, 0.5, cond)
+    tv = eng.debug_read("tv", B).transpose(0, 1, 3, 2).astype(np.float64); v = eng.debug_read("v", B).transpose(0, 1, 3, 2).astype(np.float64)
+    err = np.abs(tan - otan).reshape(B, -1).max(axis=1) / (scale + 1e-3)
+    bad = np.nonzero(err > 1e-4)[0]
+    print(f"rep {rep}: bad rows {bad[:6]}; primal drift of the same run: max rel err {np.abs(b - ob).max() / np.abs(ob).max():.1e}", flush=True)
+    for r in bad[:3]:
+        acc = np.einsum("afc,f->ac", v[r], Vr); tacc = np.einsum("afc,f->ac", tv[r], Vr)
+        acc_p = np.einsum("afc,f->ac", v_prev[r], Vr); tacc_p = np.einsum("afc,f->ac", tv_prev[r], Vr)
+        gate = np.where(np.abs(acc) > 1e-12, ob[r].astype(np.float64) / acc, 0.0).mean(axis=1)          # b = gate * acc
+        for a in range(A):
+            e = (tan[r, a] - otan[r, a]).astype(np.float64)
+            c = int(np.abs(e).argmax())
+            if np.abs(e[c]) < 1e-4 * (scale[r] + 1e-3):
+                continue
+            tgate = (otan[r, a, c] - tacc[a, c] * gate[a]) / acc[a, c]
+            h1 = tacc[a, c] * gate[a] + acc_p[a, c] * tgate          # stale v
+            h2 = tacc_p[a, c] * gate[a] + acc[a, c] * tgate          # stale tv
+            print(f"   row {r} atom {a} comp {c}: got {tan[r, a, c]:.6f} want {otan[r, a, c]:.6f} | if v stale {h1:.6f} | if tv stale {h2:.6f}", flush=True)
+            break
