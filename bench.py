@@ -156,6 +156,16 @@ def main():
         achieved = B * E_M * FLOP_PER_EDGE_LAYER / (edge_ms * 1e-3) / 1e12 if n_edge else None
         split = args.precision == "f16x2"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        # HBM bytes per edge-kernel launch from the separate rocprofv3 --pmc passes of this same workload (tools/gpu_prof.sh ->
+        # tools/pmc_summary.py -> profiles/pmc_edge_traffic.json); used only if it was measured at this batch and precision
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_edge_traffic.json")) as f:
+                pm = json.load(f)
+            if pm.get("batch") == B and pm.get("precision") == args.precision:
+                traffic = pm["read_bytes_per_launch"] + pm["write_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         rec = {
             "metric": "integration-steps/sec (whole node)", "value": value, "unit": "trajectory-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -166,7 +176,7 @@ def main():
                        "sharding": f"dp{world} over independent trajectories, final RCCL all-gather of end states"},
             "whole_step_tflops": FLOP_PER_MOL_EVAL * B * args.steps * world / elapsed / 1e12,
             "roofline": {"kernel": "painn_edge_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak if achieved else None, "traffic": None,
+                         "frac": achieved / peak if achieved else None, "traffic": traffic,
                          "peak_is": "dense fp16 MFMA (2.5 PF); the split path spends 3 fp16 products per algorithmic product, so its matrix-side ceiling is peak/3"
                                     if split else "f32 MFMA (157.3 TF)",
                          "launches": n_edge, "avg_launch_ms": edge_ms, "update_kernel_avg_ms": ms_upd / max(n_upd, 1),

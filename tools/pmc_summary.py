@@ -28,6 +28,18 @@ for k, d in C.items():
     out.append(f"| {k} | {len(D[k])} | {ms:.3f} | {clk:.2f} | {m['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles:.3f} | "
                f"{m['SQ_WAIT_INST_ANY'] / wc:.2f} / {m['SQ_WAIT_ANY'] / wc:.2f} / {m['SQ_ACTIVE_INST_ANY'] / wc:.2f} | "
                f"{m['SQ_INSTS_VALU'] / max(m.get('SQ_INSTS_MFMA', 1), 1):.2f} | {2 * m.get('FETCH_SIZE', 0) / 1024:.1f} | {m.get('WRITE_SIZE', 0) / 1024:.1f} |")
+# HBM traffic of the edge kernel per launch, launch-weighted over its variants, for bench.py's roofline.traffic
+import json, os
+tot = {"r": 0.0, "w": 0.0, "n": 0}
+for k, d in C.items():
+    if k.startswith("painn_edge_kernel") and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        n = len(d["FETCH_SIZE"])
+        tot["r"] += 2 * sum(d["FETCH_SIZE"]) * 1024; tot["w"] += sum(d["WRITE_SIZE"]) * 1024; tot["n"] += n
+if tot["n"] and os.environ.get("PMC_BATCH"):
+    json.dump({"kernel": "painn_edge_kernel", "batch": int(os.environ["PMC_BATCH"]), "precision": os.environ.get("PMC_PRECISION", "f16x2"),
+               "read_bytes_per_launch": tot["r"] / tot["n"], "write_bytes_per_launch": tot["w"] / tot["n"], "launches_measured": tot["n"],
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE (KB) doubled for 16-byte streaming reads (MI355X guide)",
+               "source": f"gpurun_out/pmc_{tag}_fetch, pmc_{tag}_write"}, open("profiles/pmc_edge_traffic.json", "w"), indent=1)
 txt = "\n".join(out)
 print(txt)
 if len(sys.argv) > 2:
