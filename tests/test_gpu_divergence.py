@@ -171,13 +171,15 @@ def test_divergence_other_widths_and_sizes_vs_oracle(F, L, A, B, variant, precis
     assert (np.abs(div - odiv) < DIV_ATOL * (np.abs(odiv) + 1.0)).all(), (div, odiv)
 
 
-def test_divergence_race_screen_full_occupancy():
+@pytest.mark.parametrize("template", ["throughput", "latency"])
+def test_divergence_race_screen_full_occupancy(template, monkeypatch):
     """256 molecules x 54 directions fill every CU with two workgroups of each tangent kernel.  During development the
     split-fp16 build of the tangent readout kernel returned wrong sums for about one 16-node tile in 2 000 in exactly this
     regime (5-10 molecules per evaluation off by 1e-3..1e-1) while every small-batch parity test passed; the f32 and split
     builds are independent instruction streams, so per-molecule agreement of repeated evaluations of both is the screen."""
     ti = pkg()
     syn, W = ti.synthetic, ti.weights
+    monkeypatch.setenv("TI_TEMPLATE", template)
     F, L, A, B = 128, 2, 18, 256
     src, dst, et = syn.fully_connected_template(A)
     flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=F + A), W.painn_param_spec(0, F, L, 25))

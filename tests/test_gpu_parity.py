@@ -169,7 +169,8 @@ def test_painn_large_batch_properties():
     assert rel_l2(b[idx], orc.drift(x[idx], 0.5, cond[idx])) < DRIFT_TOL
 
 
-def test_painn_race_screen_full_occupancy():
+@pytest.mark.parametrize("template,B", [("throughput", 16384), ("latency", 6000)])
+def test_painn_race_screen_full_occupancy(template, B, monkeypatch):
     """Every CU holds two workgroups and workgroups are replaced mid-launch (1366 workgroups, 512 resident): the weight
     stream's LDS-DMA / barrier protocol is exercised under memory load, where an early fragment read shows up as a few
     wrong molecules per launch (seen during development at ~1 in 4096; invisible at the small parity sizes).  The f32 and
@@ -177,7 +178,8 @@ def test_painn_race_screen_full_occupancy():
     screen; the absolute check against the oracle is the small-batch parity tests' job."""
     ti = pkg()
     syn, W = ti.synthetic, ti.weights
-    F, L, A, B = 128, 5, 18, 16384
+    monkeypatch.setenv("TI_TEMPLATE", template)          # both edge-row layouts (ti_internal.hpp) under full occupancy
+    F, L, A = 128, 5, 18
     src, dst, et = syn.fully_connected_template(A)
     flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=0), W.painn_param_spec(0, F, L, 25))
     x, cond = syn.molecule_coords(B, A, seed=0), syn.ambient_cond(B, A)
