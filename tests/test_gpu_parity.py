@@ -318,14 +318,18 @@ def test_adw_standard_integrator_with_dlogp_like_the_shipped_config():
 
 
 @pytest.mark.parametrize("F,L,A,B,variant,precision", [(128, 2, 18, 50, 0, "f32"), (128, 2, 18, 50, 0, "f16x2"), (64, 2, 25, 7, 1, "f32"),
-                                                       (32, 3, 9, 33, 2, "f32"), (32, 2, 4, 5, 0, "f32")])
+                                                       (32, 3, 9, 33, 2, "f32"), (32, 2, 4, 5, 0, "f32"), (32, 2, -22, 9, 0, "f32")])
 def test_edge_templates_agree(F, L, A, B, variant, precision, monkeypatch):
     """The two edge templates (ti_internal.hpp: throughput = G molecules per wave, latency = one molecule cut into parts of
     destination atoms, one wave each) evaluate the same sums in different blockings: drift, per-stage state and divergence agree
     with each other to round-off and with the oracle to the drift bar.  A = 4 has too few rows for a second template."""
     ti = pkg()
     syn, W = ti.synthetic, ti.weights
-    src, dst, et = syn.fully_connected_template(A)
+    if A < 0:                                           # a sparse graph: uneven in-degrees (1 .. ~10), parts of unequal length
+        A = -A
+        src, dst, et = syn.sparse_template(A, seed=1)
+    else:
+        src, dst, et = syn.fully_connected_template(A)
     flat = W.flatten_state_dict(syn.painn_state_dict(variant, F, L, 25, seed=F + A), W.painn_param_spec(variant, F, L, 25))
     x = syn.molecule_coords(B, A, seed=B)
     cond = [syn.ambient_cond(B, A), syn.latent_cond(B, A, 500.0), None][variant]
