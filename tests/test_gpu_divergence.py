@@ -193,3 +193,33 @@ def test_divergence_race_screen_full_occupancy(template, monkeypatch):
     for o in outs[1:]:
         bad = np.abs(o - ref) > 5e-5 * (np.abs(ref) + 1.0)
         assert not bad.any(), f"{int(bad.sum())} molecules disagree, worst {np.abs(o - ref).max():.2e}"
+
+
+@pytest.mark.parametrize("name", ["div_ambient_small", "div_latent_multi"])
+def test_ode_wrapper_mirror(name):
+    """ODEWrapper(b, return_dlogp=True)(t, (x, dlogp), batch[, n_steps]) -> (b, -div * scale) like the reference module."""
+    torch = pytest.importorskip("torch")
+    from test_gpu_api import golden_batch, state_dict_of
+    ti = pkg()
+    g = load_golden(name)
+    ambient = int(g["variant"]) == 0
+    mod = ti.thermo.ambient if ambient else ti.thermo.latent
+    kw = dict(n_features=int(g["F"]), score_layers=int(g["L"]), temp_length=int(g["temp_length"]))
+    if not ambient:
+        kw["temperatures"] = [int(x) for x in g["temperatures"]]
+    b = mod.cPaiNN(**kw)
+    b.load_state_dict(state_dict_of(g))
+    batch = golden_batch(g, "atoms" if ambient else "atom_number")
+    ode = mod.ODEWrapper(b, return_dlogp=True)
+    n_steps = [0]
+    args = (torch.tensor(float(g["t"])), (batch.x0.clone(), torch.zeros(int(g["B"]))), batch) + ((n_steps,) if ambient else ())
+    drift, negdiv = ode(*args)
+    assert rel_l2(drift.numpy().reshape(g["drift"].shape), g["drift"]) < TOL
+    scale = float(g["div_scale"])
+    assert np.allclose(negdiv.numpy(), g["negdiv_scaled"], rtol=0, atol=DIV_ATOL * scale * (np.abs(g["negdiv_scaled"]).max() / scale + 1.0))
+    if ambient:
+        assert n_steps == [0, 1]
+    rev = mod.ODEWrapper(b, return_dlogp=True, reverse_ode=True)(*args[:3])
+    assert np.allclose(rev[0].numpy(), -drift.numpy()) and np.allclose(rev[1].numpy(), -negdiv.numpy())
+    plain = mod.ODEWrapper(b)(torch.tensor(float(g["t"])), batch.x0.clone(), batch)
+    assert rel_l2(plain.numpy().reshape(g["drift"].shape), g["drift"]) < TOL

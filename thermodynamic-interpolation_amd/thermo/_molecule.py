@@ -122,6 +122,54 @@ class PaiNNShell:
     __call__ = forward
 
 
+class ODEWrapperBase:
+    """Mirror of the reference ``ODEWrapper`` (mdqm9/thermo/{ambient,latent}/models/ode_wrapper.py): the right-hand side the
+    integrator sees.  forward(t, states, batch[, n_steps]) -> b, or (b, -div * DIV_SCALE) with return_dlogp (reverse_ode:
+    (-b, +div * DIV_SCALE)); compute_divergence(b, batch) -> div * DIV_SCALE evaluated at batch.x, batch.t."""
+    DIV_SCALE = 1.0
+
+    def __init__(self, b, return_dlogp=False, reverse_ode=False):
+        self.b, self.return_dlogp, self.reverse_ode = b, return_dlogp, reverse_ode
+
+    def _eval(self, batch, x, t, with_div):
+        B, A, src, dst, ety, ids = split_batch(batch, self.b.ATOM_KEY)
+        xs = np.ascontiguousarray(C.to_numpy(x, np.float32).reshape(B, A, 3))
+        eng = self.b.engine_for(A, src, dst, ety, ids)
+        cond = self.b.cond_of(batch, B, A)
+        if with_div:
+            out, div = eng.drift_div(xs, float(t), cond)
+            return out.reshape(B * A, 3), div
+        return eng.drift(xs, float(t), cond).reshape(B * A, 3), None
+
+    def forward(self, integration_time, states, batch, n_steps=None):
+        if n_steps is not None:
+            n_steps.append(n_steps[-1] + 1)                       # ambient wrapper's evaluation counter (ode_wrapper.py:44)
+        t = float(C.to_numpy(integration_time).reshape(-1)[0])
+        if self.return_dlogp:
+            x, _ = states
+            b, div = self._eval(batch, x, t, True)
+            b, d = C.like(b, x), C.like(div * np.float32(self.DIV_SCALE), x)
+            return (b, -d) if not self.reverse_ode else (-b, d)
+        b, _ = self._eval(batch, states, t, False)
+        return C.like(b, states)
+
+    __call__ = forward
+
+    @classmethod
+    def compute_divergence(cls, b, batch):
+        t = float(C.to_numpy(batch.t).reshape(-1)[0])
+        _, div = cls(b)._eval(batch, batch.x, t, True)
+        return C.like(div * np.float32(cls.DIV_SCALE), batch.x)
+
+    @staticmethod
+    def reset_batch(batch, x, integration_time):
+        batch.x = x.clone() if hasattr(x, "clone") else np.array(x, copy=True)
+        ids = getattr(batch, "atoms", None)
+        ids = getattr(batch, "atom_number") if ids is None else ids
+        batch.t = integration_time * (ids * 0 + 1)                # integration_time * ones_like(atoms)  (ode_wrapper.py:112)
+        return batch
+
+
 class MoleculeIntegratorBase:
     """rollout(batch) with the reference's constructor.  method: 'dopri5' (the reference default; adaptive with rtol / atol, the
     grid linspace(start, end, n_step) selects the output times) or a scheme on that grid (see _common.check_method).

@@ -6,7 +6,7 @@
 from __future__ import annotations
 
 from .. import weights as _W
-from ._molecule import DEFAULT_TEMPS, MoleculeIntegratorBase, PaiNNShell
+from ._molecule import DEFAULT_TEMPS, MoleculeIntegratorBase, ODEWrapperBase, PaiNNShell
 
 
 class cPaiNN(PaiNNShell):
@@ -16,6 +16,11 @@ class cPaiNN(PaiNNShell):
                  temperatures=DEFAULT_TEMPS):
         self.embedding_layers = embedding_layers          # unused by the reference as well (dead constructor argument)
         self._init(n_features, score_layers, n_types, temp_length, time_length, temperatures)
+
+
+class ODEWrapper(ODEWrapperBase):
+    """thermo/ambient/models/ode_wrapper.py:6-113"""
+    DIV_SCALE = 1e-2
 
 
 class MoleculeIntegrator(MoleculeIntegratorBase):

@@ -6,7 +6,7 @@
 from __future__ import annotations
 
 from .. import weights as _W
-from ._molecule import DEFAULT_TEMPS, MoleculeIntegratorBase, PaiNNShell
+from ._molecule import DEFAULT_TEMPS, MoleculeIntegratorBase, ODEWrapperBase, PaiNNShell
 
 
 class cPaiNN(PaiNNShell):
@@ -18,6 +18,11 @@ class cPaiNN(PaiNNShell):
         self.VARIANT = _W.LATENT_MULTI if multi else _W.LATENT_SINGLE
         self.COND_KEYS = ("T",) if multi else ()
         self._init(n_features, score_layers, n_types, temp_length, time_length, temperatures)
+
+
+class ODEWrapper(ODEWrapperBase):
+    """thermo/latent/models/ode_wrapper.py:6-113"""
+    DIV_SCALE = 1.0
 
 
 class MoleculeIntegrator(MoleculeIntegratorBase):
