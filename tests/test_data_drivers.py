@@ -72,6 +72,33 @@ def test_dataset_layout_and_batches(tmp_path):
     assert len(lb) == 2 and lb[0].T.dtype == np.int64 and np.all(lb[0].T == 800) and hasattr(lb[0], "atom_number")
 
 
+def test_latent_to_ambient_chaining(tmp_path):
+    """use_latent_trajs: end frames of the latent sampler's output become the ambient starting points (mdqm9_ambient.py:173-199)."""
+    ti = pkg()
+    d = ti.data
+    rs = np.random.RandomState(4)
+    A, n, n_step = 9, 11, 5
+    samples = rs.standard_normal((n, n_step, A, 3)) + 3.0                 # not centred on purpose
+    dl = rs.standard_normal(n).astype(np.float32)
+    np.save(tmp_path / "samples_mol_00031_300k_forward.npy", samples)
+    np.save(tmp_path / "dlogps_mol_00031_300k_forward.npy", dl)
+    ds = d.MDQM9SamplerDataset("00031.npy", traj_path="unused", T0=300, T1=500, cutoff=1000, use_latent_trajs=True, n_latent_samples=8,
+                               latent_traj_path=str(tmp_path))
+    assert len(ds) == 8 and ds.data.shape == (8, A, 3)
+    want = samples[:8, -1] - samples[:8, -1].mean(axis=1, keepdims=True)
+    np.testing.assert_allclose(ds.data, want / d.SCALING_FACTOR, rtol=1e-6)
+    np.testing.assert_allclose(ds.data0, samples[:8, 0] - samples[:8, 0].mean(axis=1, keepdims=True), rtol=1e-5, atol=1e-6)
+    batch = next(ds.batches(4, shuffle=False))
+    np.testing.assert_allclose(batch.latent_dlogp, dl[:4])
+    assert batch.latent_z.shape == (4 * A, 3) and abs(batch.latent_z.reshape(4, A, 3).mean(axis=1)).max() < 1e-6
+    assert np.all(batch.T0 == 300.0) and np.all(batch.T1 == 500.0)
+    ds2 = d.MDQM9SamplerDataset("00031.npy", traj_path="unused", T0=300, scale=True, cutoff=1000, use_latent_trajs=True, n_latent_samples=3,
+                                latent_traj_path=str(tmp_path))
+    np.testing.assert_allclose(ds2.data, want[:3], rtol=1e-6)
+    with pytest.raises(AssertionError):
+        d.MDQM9SamplerDataset("00031.npy", traj_path="unused", use_latent_trajs=True)
+
+
 def test_load_config_reads_the_reference_json_shape(tmp_path):
     ti = pkg()
     cfg = {"seed": 0, "n_features": 128, "score_layers": 5, "temp_length": 100, "batch_size": 12, "n_steps": 100, "atol": 1e-5,

@@ -129,14 +129,40 @@ def load_trajectory(traj_path: str, split: str, traj_filename: str, T: int, scal
     return trajs.astype(np.float32)
 
 
+def load_latent_trajectory(latent_traj_path: str, traj_filename: str, T: int, n_samples: int, scale: bool):
+    """(z, x, dlogp0): first and last frame of the latent sampler's output ``samples_mol_{id}_{T}k_forward.npy``
+    [n, n_step, A, 3] and, for molecule 00031, ``dlogps_mol_{id}_{T}k_forward.npy`` (zeros otherwise); both centred, the end frames
+    divided by SCALING_FACTOR unless `scale` (get_latent_mdqm9_trajs, mdqm9_ambient.py:173-199)."""
+    assert traj_filename in {"00031.npy", "10506.npy"}
+    idx = traj_filename[:-4]
+    samples = np.load(os.path.join(latent_traj_path, f"samples_mol_{idx}_{T}k_forward.npy"), mmap_mode="r")
+    z = _remove_com(np.asarray(samples[:n_samples, 0], np.float64))
+    x = _remove_com(np.asarray(samples[:n_samples, -1], np.float64))
+    if traj_filename == "00031.npy":
+        dlogp0 = np.asarray(np.load(os.path.join(latent_traj_path, f"dlogps_mol_{idx}_{T}k_forward.npy"))[:n_samples], np.float32)
+    else:
+        dlogp0 = np.zeros(len(x), np.float32)
+    if not scale:
+        x = x / SCALING_FACTOR
+    return z.astype(np.float32), x.astype(np.float32), dlogp0
+
+
 class MDQM9SamplerDataset:
     """Ambient sampling dataset (MDQM9SamplerDataset, mdqm9_ambient.py:110-170): frames at T0 as starting points, to be carried to
-    T1.  Bonds come from a mol block (`sdf_path/sdf_filename`, record = molecule id) or are passed explicitly."""
+    T1.  Bonds come from a mol block (`sdf_path/sdf_filename`, record = molecule id) or are passed explicitly.  With
+    `use_latent_trajs` the starting points are the end states of the latent sampler (latent -> ambient chaining): its first frames
+    and dlogps travel along as `latent_z` / `latent_dlogp`."""
 
     def __init__(self, traj_filename, traj_path, split="test", T0=300, T1=400, scale=False, cutoff=np.inf, sdf_path=None,
-                 sdf_filename="mdqm9.sdf", bond_index=None, bonds=None):
+                 sdf_filename="mdqm9.sdf", bond_index=None, bonds=None, use_latent_trajs=False, n_latent_samples=10_000,
+                 latent_traj_path=""):
         assert split in {"train", "val", "test"}
-        self.data = load_trajectory(traj_path, split, traj_filename, T0, scale)
+        if use_latent_trajs:
+            assert latent_traj_path != "", "latent_traj_path must be provided if use_latent_trajs is True"
+            self.data0, self.data, self.dlogp0 = load_latent_trajectory(latent_traj_path, traj_filename, T0, n_latent_samples, scale)
+        else:
+            self.data = load_trajectory(traj_path, split, traj_filename, T0, scale)
+            self.data0, self.dlogp0 = np.zeros_like(self.data), np.zeros(len(self.data), np.float32)      # dummies, like the reference
         self.T0, self.T1 = float(T0), float(T1)
         if bond_index is None and sdf_path is not None:
             bond_index, bonds = bonds_from_molblock(read_sdf_record(os.path.join(sdf_path, sdf_filename), int(traj_filename.split(".")[0])))
@@ -152,7 +178,8 @@ class MDQM9SamplerDataset:
             idx = order[i:i + batch_size]
             if drop_last and len(idx) < batch_size:
                 return
-            yield make_batch("ambient", self.data[idx], self.template, T0=self.T0, T1=self.T1, atom_ids=self.atom_ids)
+            yield make_batch("ambient", self.data[idx], self.template, T0=self.T0, T1=self.T1, atom_ids=self.atom_ids,
+                             latent_z=self.data0[idx], latent_dlogp=self.dlogp0[idx])
 
 
 class LatentSamplerDataset:
