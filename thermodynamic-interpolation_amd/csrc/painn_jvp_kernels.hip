@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_JVP_EDGE_OCC : 1)) void painn_j
             d0 = ta0 * B0 + A0 * (dd * Q0); d1 = ta1 * B1 + A1 * (dd * Q1);
         };
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
-            const f32x4 s0 = r16::select_sum<false>(sel, v0), s1 = r16::select_sum<false>(sel, v1);   // f32 products: the fp16 form costs this kernel its registers
+            // f32 products: with the fp16 form (select_sum<true>) hipcc needs 346 registers for this kernel (824 spilled at two
+            // waves per SIMD), although the same call costs the primal edge kernel nothing
+            const f32x4 s0 = r16::select_sum<false>(sel, v0), s1 = r16::select_sum<false>(sel, v1);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (snode[r] >= 0) { float* d = dst + (size_t)snode[r] * stride; add_noret(d, s0[r]); add_noret(d + 16, s1[r]); }
