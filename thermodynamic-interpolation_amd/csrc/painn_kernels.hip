@@ -114,25 +114,38 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 #endif
 
 // One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
-// 4 waves per workgroup share the weight-chunk stream; 2 workgroups per CU (F <= 128) run out of phase and hide each
-// other's LayerNorm / reduction / wait phases behind matrix work.
+// The waves of a workgroup share the weight-chunk stream (edge_waves below); two waves per SIMD (F <= 128) hide each other's
+// LayerNorm / reduction / wait phases behind matrix work.
 // SPLIT selects the split-fp16 matrix path (mfma_chain.hpp: Opnd<NBK, true>) instead of the f32 MFMA.
 #ifndef TI_EDGE_OCC
 #define TI_EDGE_OCC 2
 #endif
+#ifndef TI_EDGE_SC4            // 1: with 8-wave workgroups at F = 128 stage four chunks per barrier (needs chunk counts % 4 == 0: 56/48/40/32)
+#define TI_EDGE_SC4 0
+#endif
+#ifndef TI_EDGE_WAVES          // waves per workgroup that share one weight stream (experiment knob; 8 -> one 512-thread workgroup per CU)
+#define TI_EDGE_WAVES 4
+#endif
+// Experiment knobs.  TI_EDGE_WAVES=8 (one 512-thread workgroup per CU sharing one weight stream: half the LDS-DMA writes) with
+// TI_EDGE_SC4=1 (4-chunk superchunks in the freed LDS: half the barriers) gains 1.7-1.9 % on the edge kernel at B >= 32k, but
+// the fatter workgroups cost the latency regime 20-60 % (A=18, B=256: 3.0 -> 4.8 ms), so 4 waves stay the default.
+// F = 256 needs the 512-register budget of one wave per SIMD and is always 4 waves.
+__host__ __device__ constexpr int edge_waves(int NBK) { return NBK <= 8 ? TI_EDGE_WAVES : 4; }
+__host__ __device__ constexpr int edge_superchunk(int NB) { return (TI_EDGE_SC4 && TI_EDGE_WAVES == 8 && NB == 4) ? 4 : 2; }
 template <int NBK, bool FIRST, bool LAST, bool SPLIT>
-__global__ __launch_bounds__(256, (NBK <= 8 ? TI_EDGE_OCC : 1)) void painn_edge_kernel(const EdgeParams p)
+__global__ __launch_bounds__(64 * edge_waves(NBK), (NBK <= 8 ? TI_EDGE_OCC * 4 / TI_EDGE_WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
 {
-    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = edge_waves(NBK), T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
     using OP = r16::Opnd<NBK, SPLIT>;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    float* scratch = reinterpret_cast<float*>(lds + 4 * CH4) + wave * 64;          // [16 rows][4] edge_dir of the block
-    float* vec = reinterpret_cast<float*>(lds + 4 * CH4) + WAVES * 64;             // [EV::COUNT][F]
+    constexpr int SC = edge_superchunk(NB);                                         // weight chunks per barrier
+    float* scratch = reinterpret_cast<float*>(lds + 2 * SC * CH4) + wave * 64;     // [16 rows][4] edge_dir of the block
+    float* vec = reinterpret_cast<float*>(lds + 2 * SC * CH4) + WAVES * 64;        // [EV::COUNT][F]
     for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    PipeDMA<NB, T, 2> pipe;                                                      // weights staged two chunks per barrier
+    PipeDMA<NB, T, SC> pipe;                                                     // weights staged SC chunks per barrier
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);   // barrier inside: vec is visible after it
 
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
@@ -597,7 +610,7 @@ static hipError_t set_lds(K kernel, size_t bytes)
 }
 
 // edge kernel LDS: two superchunks of two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors
-static size_t edge_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 4 * 256 + 21 * (size_t)32 * NB * 4; }
+static size_t edge_lds_bytes(int NB) { return 2 * edge_superchunk(NB) * (size_t)256 * NB * 16 + edge_waves(2 * NB) * 256 + 21 * (size_t)32 * NB * 4; }
 
 static size_t update_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 10 * (size_t)32 * NB * 4; }
 
@@ -668,18 +681,19 @@ hipError_t launch_edge(int NBv, bool first, bool last, bool split, const EdgePar
 {
     TI_DISPATCH_NB(NBv, {
         (void)WAVES;
-        const dim3 g((unsigned)((p.n_groups + 3) / 4));          // 4 waves (= 4 molecule groups) per workgroup
+        constexpr int EW = edge_waves(2 * NB);
+        const dim3 g((unsigned)((p.n_groups + EW - 1) / EW));          // one wave (= one group) each
         const size_t l = edge_lds_bytes(NB);
         if (split) {
-            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true>), g, dim3(256), l, st, p);
-            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true>), g, dim3(256), l, st, p);
-            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true>), g, dim3(256), l, st, p);
-            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true>), g, dim3(256), l, st, p);
+            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true>), g, dim3(64 * EW), l, st, p);
+            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true>), g, dim3(64 * EW), l, st, p);
+            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true>), g, dim3(64 * EW), l, st, p);
+            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true>), g, dim3(64 * EW), l, st, p);
         } else {
-            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false>), g, dim3(256), l, st, p);
-            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false>), g, dim3(256), l, st, p);
-            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false>), g, dim3(256), l, st, p);
-            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false>), g, dim3(256), l, st, p);
+            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false>), g, dim3(64 * EW), l, st, p);
+            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false>), g, dim3(64 * EW), l, st, p);
+            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false>), g, dim3(64 * EW), l, st, p);
+            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false>), g, dim3(64 * EW), l, st, p);
         }
     });
     return hipGetLastError();
