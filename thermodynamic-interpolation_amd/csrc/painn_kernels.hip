@@ -114,33 +114,27 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 #endif
 
 // One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
-// The waves of a workgroup share the weight-chunk stream (edge_waves below); two waves per SIMD (F <= 128) hide each other's
+// The waves of a workgroup share the weight-chunk stream (4 or 8 of them, see below); two waves per SIMD (F <= 128) hide each other's
 // LayerNorm / reduction / wait phases behind matrix work.
 // SPLIT selects the split-fp16 matrix path (mfma_chain.hpp: Opnd<NBK, true>) instead of the f32 MFMA.
 #ifndef TI_EDGE_OCC
 #define TI_EDGE_OCC 2
 #endif
-#ifndef TI_EDGE_SC4            // 1: with 8-wave workgroups at F = 128 stage four chunks per barrier (needs chunk counts % 4 == 0: 56/48/40/32)
-#define TI_EDGE_SC4 0
-#endif
-#ifndef TI_EDGE_WAVES          // waves per workgroup that share one weight stream (experiment knob; 8 -> one 512-thread workgroup per CU)
-#define TI_EDGE_WAVES 4
-#endif
-// Experiment knobs.  TI_EDGE_WAVES=8 (one 512-thread workgroup per CU sharing one weight stream: half the LDS-DMA writes) with
-// TI_EDGE_SC4=1 (4-chunk superchunks in the freed LDS: half the barriers) gains 1.7-1.9 % on the edge kernel at B >= 32k, but
-// the fatter workgroups cost the latency regime 20-60 % (A=18, B=256: 3.0 -> 4.8 ms), so 4 waves stay the default.
-// F = 256 needs the 512-register budget of one wave per SIMD and is always 4 waves.
-__host__ __device__ constexpr int edge_waves(int NBK) { return NBK <= 8 ? TI_EDGE_WAVES : 4; }
-__host__ __device__ constexpr int edge_superchunk(int NB) { return (TI_EDGE_SC4 && TI_EDGE_WAVES == 8 && NB == 4) ? 4 : 2; }
-template <int NBK, bool FIRST, bool LAST, bool SPLIT>
-__global__ __launch_bounds__(64 * edge_waves(NBK), (NBK <= 8 ? TI_EDGE_OCC * 4 / TI_EDGE_WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
+// Workgroup width.  4 waves (two workgroups per CU) is the default; for large launches (>= 2048 groups, F <= 128) the launcher
+// picks the 8-wave build: one 512-thread workgroup per CU shares one weight stream (half the LDS-DMA writes) and, at F = 128,
+// the freed LDS holds 4-chunk superchunks (half the barriers; needs chunk counts % 4 == 0: 56/48/40/32) -- 1.8 % on the edge
+// kernel at B >= 32k.  Small launches keep 4 waves: fatter workgroups cost the latency regime 20-60 %.  F = 256 needs the
+// 512-register budget of one wave per SIMD and is always 4 waves.
+__host__ __device__ constexpr int edge_superchunk(int NB, int WAVES) { return (WAVES == 8 && NB == 4) ? 4 : 2; }
+template <int NBK, bool FIRST, bool LAST, bool SPLIT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? TI_EDGE_OCC * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
 {
-    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = edge_waves(NBK), T = 64 * WAVES, CH4 = 256 * NB;
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
     using OP = r16::Opnd<NBK, SPLIT>;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    constexpr int SC = edge_superchunk(NB);                                         // weight chunks per barrier
+    constexpr int SC = edge_superchunk(NB, WAVES);                                  // weight chunks per barrier
     float* scratch = reinterpret_cast<float*>(lds + 2 * SC * CH4) + wave * 64;     // [16 rows][4] edge_dir of the block
     float* vec = reinterpret_cast<float*>(lds + 2 * SC * CH4) + WAVES * 64;        // [EV::COUNT][F]
     for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
@@ -610,9 +604,25 @@ static hipError_t set_lds(K kernel, size_t bytes)
 }
 
 // edge kernel LDS: two superchunks of two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors
-static size_t edge_lds_bytes(int NB) { return 2 * edge_superchunk(NB) * (size_t)256 * NB * 16 + edge_waves(2 * NB) * 256 + 21 * (size_t)32 * NB * 4; }
+static size_t edge_lds_bytes(int NB, int WAVES) { return 2 * edge_superchunk(NB, WAVES) * (size_t)256 * NB * 16 + WAVES * 256 + 21 * (size_t)32 * NB * 4; }
 
 static size_t update_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 10 * (size_t)32 * NB * 4; }
+
+template <int NB, int EW>
+static hipError_t configure_edge()
+{
+    const size_t be = edge_lds_bytes(NB, EW);
+    hipError_t e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, false, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, false, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, false, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, false, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, true, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, true, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, true, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, true, EW>, be)) != hipSuccess) return e;
+    return hipSuccess;
+}
 
 template <int NB, int WAVES>
 static hipError_t configure_nb()
@@ -621,15 +631,8 @@ static hipError_t configure_nb()
     hipError_t e;
 #define TI_SET(k) if ((e = set_lds(k, b)) != hipSuccess) return e
     TI_SET((painn_embed_kernel<NB, WAVES, 2>)); TI_SET((painn_embed_kernel<NB, WAVES, 3>)); TI_SET((painn_embed_kernel<NB, WAVES, 4>));
-    const size_t be = edge_lds_bytes(NB);
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, false>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, false>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, false>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, false>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, true>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, true>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, true>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, true>, be)) != hipSuccess) return e;
+    if ((e = configure_edge<NB, 4>()) != hipSuccess) return e;
+    if constexpr (NB <= 4) { if ((e = configure_edge<NB, 8>()) != hipSuccess) return e; }
     const size_t bu = update_lds_bytes(NB);
     if ((e = set_lds(painn_update_kernel<2 * NB, true, false>, bu)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, false, false>, bu)) != hipSuccess) return e;
@@ -677,24 +680,31 @@ hipError_t launch_embed(int NBv, int nseg, const EmbedParams& p, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int NB, int EW>
+static void launch_edge_w(bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
+{
+    const dim3 g((unsigned)((p.n_groups + EW - 1) / EW)), t(64 * EW);          // one wave (= one group or part) each
+    const size_t l = edge_lds_bytes(NB, EW);
+    if (split) {
+        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true, EW>), g, t, l, st, p);
+        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true, EW>), g, t, l, st, p);
+        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true, EW>), g, t, l, st, p);
+        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true, EW>), g, t, l, st, p);
+    } else {
+        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false, EW>), g, t, l, st, p);
+        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false, EW>), g, t, l, st, p);
+        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false, EW>), g, t, l, st, p);
+        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false, EW>), g, t, l, st, p);
+    }
+}
+
 hipError_t launch_edge(int NBv, bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
 {
+    const bool wide = p.n_groups >= 2048;          // enough groups to fill every CU with 8-wave workgroups
     TI_DISPATCH_NB(NBv, {
         (void)WAVES;
-        constexpr int EW = edge_waves(2 * NB);
-        const dim3 g((unsigned)((p.n_groups + EW - 1) / EW));          // one wave (= one group) each
-        const size_t l = edge_lds_bytes(NB);
-        if (split) {
-            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true>), g, dim3(64 * EW), l, st, p);
-            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true>), g, dim3(64 * EW), l, st, p);
-            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true>), g, dim3(64 * EW), l, st, p);
-            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true>), g, dim3(64 * EW), l, st, p);
-        } else {
-            if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false>), g, dim3(64 * EW), l, st, p);
-            else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false>), g, dim3(64 * EW), l, st, p);
-            else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false>), g, dim3(64 * EW), l, st, p);
-            else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false>), g, dim3(64 * EW), l, st, p);
-        }
+        if (NB <= 4 && wide) launch_edge_w<NB, (NB <= 4 ? 8 : 4)>(first, last, split, p, st);
+        else launch_edge_w<NB, 4>(first, last, split, p, st);
     });
     return hipGetLastError();
 }
