@@ -358,3 +358,31 @@ def test_edge_templates_agree(F, L, A, B, variant, precision, monkeypatch):
     assert rel_l2(res["latency"][0], res["throughput"][0]) < 2e-6
     assert rel_l2(res["latency"][2], res["throughput"][2]) < 2e-6
     assert np.abs(res["latency"][3] - res["throughput"][3]).max() < 2e-5 * (np.abs(res["throughput"][3]).max() + 1.0)
+
+
+@pytest.mark.parametrize("F", [32, 64])
+def test_wide_workgroups_at_small_feature_widths(F, monkeypatch):
+    """Launches with >= 2048 molecule groups use the 8-wave edge kernels (painn_kernels.hip: launch_edge); the headline shape
+    covers F = 128 (race screen above), this covers the F = 32 / 64 builds, whose weight superchunks stay two chunks deep."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    monkeypatch.setenv("TI_TEMPLATE", "throughput")
+    L, A, B = 2, 6, 8 * 2048 + 5                       # E = 30 -> G = 8 molecules per group (240 rows, no padding): 2049 groups
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=F), W.painn_param_spec(0, F, L, 25))
+    x, cond = syn.molecule_coords(B, A, seed=1), syn.ambient_cond(B, A)
+    orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+    idx = np.r_[0:40, B - 40:B]
+    ref = orc.drift(x[idx], 0.3, cond[idx])
+    outs = {}
+    for prec in ("f32", "f16x2"):
+        eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision=prec)
+        b = eng.drift(x, 0.3, cond)
+        assert rel_l2(b[idx], ref) < DRIFT_TOL, prec
+        np.testing.assert_array_equal(eng.drift(x, 0.3, cond), b)
+        # the same molecules through the narrow build (a batch below the threshold): same sums, same order -> bit for bit
+        np.testing.assert_array_equal(eng.drift(x[:800], 0.3, cond[:800]), b[:800])
+        outs[prec] = b.reshape(B, -1)
+        eng.close()
+    per_mol = np.linalg.norm(outs["f16x2"] - outs["f32"], axis=1) / np.linalg.norm(outs["f32"], axis=1)
+    assert per_mol.max() < 3e-5
