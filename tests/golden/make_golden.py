@@ -342,6 +342,7 @@ def div_cases():
     painn_div_case("div_ambient_f128", W.AMBIENT, 128, 3, 6, 2, fc(6), 100, TEMPS, seed=11, traj_steps=3)
     painn_div_case("div_latent_multi", W.LATENT_MULTI, 32, 2, 6, 2, fc(6), 75, TEMPS, seed=7, sigma=1.0)
     painn_div_case("div_latent_single", W.LATENT_SINGLE, 64, 2, 4, 2, fc(4), 75, [800], seed=8, sigma=1.0)
+    painn_div_case("div_ambient_full", W.AMBIENT, 128, 5, 18, 1, fc(18), 100, TEMPS, seed=0, traj_steps=2)      # the headline shape
 
 
 TEMPS = [300, 400, 500, 600, 700, 800, 900, 1000]
@@ -350,6 +351,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if "--div-only" in sys.argv:      # only the divergence fixtures (the drift fixtures above are unchanged by them)
         div_cases()
+        sys.exit(0)
+    if "--div-full-only" in sys.argv:
+        painn_div_case("div_ambient_full", W.AMBIENT, 128, 5, 18, 1, syn.fully_connected_template(18), 100, TEMPS, seed=0, traj_steps=2)
         sys.exit(0)
     fc = syn.fully_connected_template
     # --- ambient (mdqm9/thermo/ambient)

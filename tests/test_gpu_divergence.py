@@ -52,6 +52,23 @@ def test_jvp_stage_taps_vs_oracle(name, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_divergence_headline_shape_vs_reference_autograd(precision):
+    """F = 128, L = 5, A = 18: divergence and two-state Euler / Heun step against the reference's autograd fixture."""
+    g = load_golden("div_ambient_full")
+    eng, _ = make_pair(g, precision)
+    scale = float(g["div_scale"])
+    ref_div = -g["negdiv_scaled"].astype(np.float64) / scale
+    b, div = eng.drift_div(g["x"], float(g["t"]), g["cond"])
+    assert rel_l2(b, g["drift"]) < TOL
+    assert (np.abs(div - ref_div) < DIV_ATOL * (np.abs(ref_div) + 1.0)).all(), (div, ref_div)
+    for scheme in ("euler", "heun"):
+        path, dl, _ = eng.rollout_dlogp(g["x"], g["cond"], g["grid"], scheme=scheme, div_scale=scale)
+        ref, ref_dl = g[f"traj_{scheme}"], g[f"dlogp_{scheme}"]
+        assert rel_l2(path - path[0], ref - ref[0]) < 2e-5
+        assert (np.abs(dl - ref_dl) < DIV_ATOL * scale * (np.abs(ref_dl) / scale + 1.0)).all(), (scheme, dl, ref_dl)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
 @pytest.mark.parametrize("name", DIV_CASES)
 def test_divergence_vs_reference_autograd(name, precision):
     g = load_golden(name)

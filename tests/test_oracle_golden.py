@@ -170,3 +170,15 @@ def test_painn_dlogp_trajectory(name, scheme):
         last, dl_last, _ = o.rollout_dlogp(g["x"], g["cond"], grid, scheme=scheme, save_every=0, div_scale=scale, reverse_ode=rev)
         np.testing.assert_array_equal(last[0], path[-1])
         np.testing.assert_array_equal(dl_last[0], dl[-1])
+
+
+def test_painn_divergence_headline_shape_matches_reference_autograd():
+    """F = 128, L = 5, A = 18 (the bench shape), one molecule: 54 reference double-backward passes vs 54 oracle forward-mode
+    passes.  fp32 oracle only (the fp64 pass and the rollouts of this size are left to the GPU suite: ~30 s each on 8 cores)."""
+    g = load_golden("div_ambient_full")
+    o = make_oracle(g)
+    scale = float(g["div_scale"])
+    ref_div = -g["negdiv_scaled"].astype(np.float64) / scale
+    b32, d32 = o.drift_div(g["x"], float(g["t"]), g["cond"], precision=32)
+    assert rel_l2(b32, g["drift"]) < TOL_BAR
+    assert (np.abs(d32 - ref_div) < DIV_ATOL * (np.abs(ref_div) + 1.0)).all(), (d32, ref_div)
