@@ -120,8 +120,8 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 #ifndef TI_EDGE_OCC
 #define TI_EDGE_OCC 2
 #endif
-// Workgroup width.  4 waves (two workgroups per CU) is the default; for large launches (>= 2048 groups, F <= 128) the launcher
-// picks the 8-wave build: one 512-thread workgroup per CU shares one weight stream (half the LDS-DMA writes) and, at F = 128,
+// Workgroup width.  4 waves (two workgroups per CU) is the default; for large split-fp16 launches (>= 2048 groups, F <= 128)
+// the launcher picks the 8-wave build: one 512-thread workgroup per CU shares one weight stream (half the LDS-DMA writes) and, at F = 128,
 // the freed LDS holds 4-chunk superchunks (half the barriers; needs chunk counts % 4 == 0: 56/48/40/32) -- 1.8 % on the edge
 // kernel at B >= 32k.  Small launches keep 4 waves: fatter workgroups cost the latency regime 20-60 %.  F = 256 needs the
 // 512-register budget of one wave per SIMD and is always 4 waves.
@@ -700,7 +700,8 @@ static void launch_edge_w(bool first, bool last, bool split, const EdgeParams& p
 
 hipError_t launch_edge(int NBv, bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
 {
-    const bool wide = p.n_groups >= 2048;          // enough groups to fill every CU with 8-wave workgroups
+    // split-fp16 path only: the f32 path is matrix-bound and loses 4 % to the wider barriers (74.2 -> 77.2 ms per launch)
+    const bool wide = split && p.n_groups >= 2048;          // enough groups to fill every CU with 8-wave workgroups
     TI_DISPATCH_NB(NBv, {
         (void)WAVES;
         if (NB <= 4 && wide) launch_edge_w<NB, (NB <= 4 ? 8 : 4)>(first, last, split, p, st);
