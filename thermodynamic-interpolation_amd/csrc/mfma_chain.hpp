@@ -395,6 +395,10 @@ __device__ __forceinline__ void load_set(Act<NBK>& a, const float* p, int q)
 template <int NBK>
 __device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const float* beta, int q)
 {
+#ifdef TI_ABL_NOLN             // ablation build (timing only, wrong results): no LayerNorm / SiLU arithmetic
+    (void)gamma; (void)beta; (void)q;
+    return;
+#endif
     constexpr float invF = 1.0f / (16.0f * NBK);
     float sum = 0.f;
 #pragma unroll
@@ -421,6 +425,11 @@ template <int NBK>
 __device__ __forceinline__ void posenc_set(Act<NBK>& a, float x_over_len, int q)
 {
     constexpr float PI_F = 3.14159265358979323846f;
+#ifdef TI_ABL_NOSINCOS         // ablation build (timing only, wrong results): no sin / cos
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) a.b[nb] = f32x4{x_over_len, (float)q, x_over_len, 1.0f};
+    return;
+#endif
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
         const int m = 4 * nb + q;
@@ -572,6 +581,11 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
     h8 hi[NBK / 2], lo[NBK / 2];
     __device__ __forceinline__ void set(const Act<NBK>& x)
     {
+#ifdef TI_ABL_NOCVT            // ablation build (timing only, wrong results): no hi / lo conversion arithmetic
+#pragma unroll
+        for (int m = 0; m < NBK / 2; ++m) { hi[m] = __builtin_bit_cast(h8, x.b[2 * m]); lo[m] = __builtin_bit_cast(h8, x.b[2 * m + 1]); }
+        return;
+#endif
 #pragma unroll
         for (int m = 0; m < NBK / 2; ++m)
 #pragma unroll
@@ -591,12 +605,20 @@ __device__ __forceinline__ void gemm_split_block(f32x4& acc, const Opnd<NBK, tru
 {
     constexpr int KS = NBK / 2;
     f32x4 x = {0, 0, 0, 0};
+#ifdef TI_ABL_NOWLO            // ablation build (timing only, wrong results): half the LDS fragment reads, same matrix work
+    h8 wh = wl[lane], wlo = wh;
+#else
     h8 wh = wl[lane], wlo = wl[64 + lane];
+#endif
 #pragma unroll
     for (int m = 0; m < KS; ++m) {
         // fragment of the next k-step is read ahead; the compiler barrier keeps hipcc from hoisting ALL reads (64 VGPRs)
         const int nx = m + 1 < KS ? m + 1 : m;
+#ifdef TI_ABL_NOWLO
+        const h8 nh = wl[(nx * 2 + 0) * 64 + lane], nl = nh;
+#else
         const h8 nh = wl[(nx * 2 + 0) * 64 + lane], nl = wl[(nx * 2 + 1) * 64 + lane];
+#endif
 #ifndef TI_NO_LDS_FENCE
         asm volatile("" ::: "memory");
 #endif
