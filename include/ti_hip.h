@@ -130,7 +130,7 @@ int ti_adw_drift_div(ti_handle* h, const float* x, float t, const float* beta0, 
 int ti_adw_rollout(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* beta0, const float* beta1,
                    int64_t B, float* out_path, int64_t* n_fevals);
 /* StandardIntegrator(return_dlogp=True) (adw/thermo/integrators.py:38-68): integrates the second state
- * d(dlogp)/dt = -div * 1e-2 with the same scheme and writes out_dlogp [rows, B] = dlogp * 1e2 */
+ * d(dlogp)/dt = -div * 1e-2 with the same scheme (any but EM with eps > 0) and writes out_dlogp [rows, B] = dlogp * 1e2 */
 int ti_adw_rollout_dlogp(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* beta0, const float* beta1,
                          int64_t B, float* out_path, float* out_dlogp, int64_t* n_fevals);
 
@@ -143,7 +143,7 @@ ti_handle* ti_painn_create(const ti_painn_desc* desc, const float* weights, size
                            const int32_t* atom_ids, int device);
 /* x: [B,A,3]; cond: [B,A,n_cond] per-node conditioning (ambient: T0,T1; latent multi-T: T; single-T: NULL); out: [B,A,3] */
 int ti_painn_drift(ti_handle* h, const float* x, float t, const float* cond, int64_t B, float* out, int mem);
-/* out_path: [rows, B, A, 3] */
+/* out_path: [rows, B, A, 3]; *n_fevals = drift evaluations taken (DOPRI5: 2 + 6 per attempted step) */
 int ti_painn_rollout(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* cond, int64_t B,
                      float* out_path, int64_t* n_fevals);
 
@@ -157,7 +157,7 @@ int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t,
  * molecules sized to TI_JVP_WS_GB gigabytes of HBM (environment, default 48). */
 int ti_painn_drift_div(ti_handle* h, const float* x, float t, const float* cond, int64_t B, float* out, float* out_div, int mem);
 /* MoleculeIntegrator.rollout(return_dlogp=True) (ambient/integrators.py:36-68, latent/integrators.py:57-89) on the fixed
- * grid of `desc` (EULER or HEUN; EM is refused): second state d(dlogp)/dt = -div_scale * div, or with reverse_ode the pair
+ * grid of `desc` (EULER, HEUN, MIDPOINT, RK4 or the adaptive DOPRI5; EM is refused): second state d(dlogp)/dt = -div_scale * div, or with reverse_ode the pair
  * (-b, +div_scale * div) (ode_wrapper.py:49; the caller passes the descending grid linspace(end, start)).
  * out_dlogp [rows, B] = state * out_scale.  Reference values: ambient div_scale 1e-2, out_scale 1e2; latent 1, 1. */
 int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* desc, const float* x0, const float* cond, int64_t B,
