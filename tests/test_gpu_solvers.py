@@ -98,6 +98,8 @@ def test_adw_dopri5_and_default_integrator():
         b, div = orc.drift_div(y[0].astype(np.float64), t, b0.astype(np.float64), b1.astype(np.float64))
         return [b.astype(np.float32), (-div * 1e-2).astype(np.float32)]
 
+    with pytest.raises(ti._lib.TiError):                       # dlogp needs a deterministic flow
+        eng.rollout(x0, b0, b1, grid, scheme="em", eps=0.1, return_dlogp=True)
     sol, nfe_ref = ode.odeint(f, [x0, np.zeros_like(x0)], grid, "dopri5", tol, tol)
     assert np.abs(path - sol[0]).max() < 20 * tol and np.abs(dl - sol[1] * 1e2).max() < 20 * tol * 1e2
     assert abs(nfe - nfe_ref) <= 12

@@ -1313,6 +1313,8 @@ static int adw_rollout_impl(ti_handle* h, const ti_rollout_desc* rd, const float
     if (!h || h->kind != 1) return fail(TI_E_ARG, "not an adw handle");
     if (int rc = check_rollout_desc(rd)) return rc;
     if (B < 0 || (B > 0 && (!x0 || !beta0 || !beta1 || !out_path))) return fail(TI_E_ARG, "NULL buffer");
+    if (out_dlogp && rd->scheme == TI_SCHEME_EM && rd->eps > 0.f)
+        return fail(TI_E_UNSUPPORTED, "dlogp is defined for a deterministic flow: EM needs eps = 0");
     if (B == 0) { if (n_fevals) *n_fevals = 0; return TI_OK; }
     return guarded([&]() -> int {
         set_device(h);
