@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libti_hip.so")
+# TI_LIB_PATH: explicit path of an alternative build of the library (tools/variant_bench.py builds experiment variants next to
+# the product library instead of over it).  Unset in normal use.
+SO_PATH = os.environ.get("TI_LIB_PATH") or os.path.join(HERE, "libti_hip.so")
 
 TI_OK, TI_E_ARG, TI_E_HIP, TI_E_NAN, TI_E_ALLOC, TI_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1

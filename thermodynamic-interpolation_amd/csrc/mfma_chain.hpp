@@ -35,7 +35,28 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 // row of the 32x32 accumulator held in register i of lane-half h
 __device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// ---- cross-lane exchanges on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap), never through the LDS crossbar.
+//   swap16(a, b): the odd 16-lane rows of a <-> the even rows of b;   swap32(a, b): rows 2,3 of a <-> rows 0,1 of b.
+// Why not __shfl_xor (ds_bpermute_b32): a ds_bpermute that is still outstanding when EXEC is narrowed returns wrong data on
+// gfx950 -- lanes switched off after issue no longer contribute their value.  hipcc schedules exactly that
+// (ds_bpermute; s_and_saveexec; ...; s_waitcnt lgkmcnt(0)) whenever a reduced value is first used inside a divergent `if`,
+// and it goes wrong once another workgroup keeps the CU's LDS queue busy: the split-fp16 tangent readout kernel lost the
+// (Vr . v) sum of whole 16-node tiles that way (140-170 of 256 molecules per evaluation at two waves per SIMD,
+// 0 with the sums materialised before the branch, 0 with these swaps).  The swaps are in-order VALU instructions: no
+// counter, no LDS round trip (~100 cycles each in every LayerNorm), same summation order as before.
+// Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) drops the second result of the builtin when both are
+// bit-cast to float and used in arithmetic (it emits r0 + r0; seen in the .s).  `s_nop 1` = the two wait states between a VALU
+// write of either operand and the swap (cdna_hip_programming.md T21); hipcc pads nothing inside asm.
+__device__ __forceinline__ void lane_swap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+// v + (the value of the lane 32 away), in every lane
+__device__ __forceinline__ float xhalf_sum(float v)
+{
+    float a = v, b = v;
+    lane_swap32(a, b);              // a = [lo, lo], b = [hi, hi]
+    return a + b;
+}
 
 // ------------------------------------------------------------------------------------------------ weight chunk pipe
 // A "logical chunk" is 256*NB float4 (32 output features x F inputs).  SC logical chunks are staged per barrier interval
@@ -251,7 +272,7 @@ __device__ __forceinline__ void ln_silu(Act<NB>& a, const float* __restrict__ ga
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) sum += a.b[nb][i];
-    sum += xhalf(sum);
+    sum = xhalf_sum(sum);
     const float mean = sum * invF;
     float var = 0.f;
 #pragma unroll
@@ -261,7 +282,7 @@ __device__ __forceinline__ void ln_silu(Act<NB>& a, const float* __restrict__ ga
             const float d = a.b[nb][i] - mean;
             var = fmaf(d, d, var);
         }
-    var += xhalf(var);
+    var = xhalf_sum(var);
     const float rstd = 1.0f / sqrtf(var * invF + 1e-5f);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -322,7 +343,7 @@ __device__ __forceinline__ float dot_set(const Act<NB>& a, const float* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc = fmaf(a.b[nb][i], w[i], acc);
     }
-    return acc + xhalf(acc);
+    return xhalf_sum(acc);
 }
 
 
@@ -346,8 +367,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 // sum over the 4 lane-quarters that share a row (lanes j, j+16, j+32, j+48), fixed order
 __device__ __forceinline__ float xquarters(float v)
 {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    float a = v, b = v;
+    lane_swap16(a, b);              // a = [v0, v0, v2, v2], b = [v1, v1, v3, v3]   (v_k = the value in lane row k)
+    a += b; b = a;
+    lane_swap32(a, b);              // a = [s01, s01, s01, s01], b = [s23, s23, s23, s23]
+    return a + b;                   // (v0 + v1) + (v2 + v3) in every lane
 }
 
 // two 16-feature output blocks of one chunk; the two accumulator chains are independent and interleaved, which covers the
@@ -677,6 +701,46 @@ __device__ __forceinline__ f32x4 select_sum(const f32x4& sel, const f32x4& v)
     for (int r = 0; r < 4; ++r) s = mfma16(sel[r], v[r], s);
     return s;
 }
+
+// ---- per-slot row sums of flipped-layout blocks without the matrix core.  A block of 16 edge rows holds at most NS destination
+// atoms ("slots" 0..NS-1; the template builder guarantees NS <= 4).  Lane (n, q) holds rows 4q + r of feature n in v[r].
+//   partial  P_k = sum_r msk[k][r] v[r]                              (rows of slot k among this lane's four; msk is 0 / 1)
+//   v_permlane16_swap(a, b): odd 16-lane rows of a <-> even rows of b;  a + b afterwards = [a0+a1, b0+b1, a2+a3, b2+b3]
+//   v_permlane32_swap(a, b): rows 2,3 of a <-> rows 0,1 of b;           a + b afterwards = [a0+a2, a1+a3, b0+b2, b1+b3]
+// so two exchange levels leave, in lane row (quarter) q, the full 16-row sum of ONE of four inputs: NS = 4: the four slots of
+// one value; NS = 2: slots {0,1} of v0 in quarters {0,1} and of v1 in quarters {2,3}.  Fixed order -> deterministic; one atomic
+// instruction then adds every slot of the block.  Replaces the 16x16 selection product (two fp16 MFMAs + a hi/lo conversion of
+// the values per sum in split mode, four f32 MFMAs otherwise) and its four sparsely populated atomics per sum.
+template <int NS>
+struct QuarterSum {
+    static_assert(NS == 2 || NS == 4, "2 or 4 slots per row block");
+    float msk[NS][4];
+    __device__ __forceinline__ static constexpr int slot_of_quarter(int q) { return NS == 2 ? (q & 1) : q; }
+    __device__ __forceinline__ void set_row(int r, int slot)
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) msk[k][r] = slot == k ? 1.0f : 0.0f;
+    }
+    __device__ __forceinline__ float partial(int k, const f32x4& v) const
+    {
+        return fmaf(msk[k][3], v[3], fmaf(msk[k][2], v[2], fmaf(msk[k][1], v[1], msk[k][0] * v[0])));
+    }
+    __device__ __forceinline__ static float swap16_add(float a, float b) { lane_swap16(a, b); return a + b; }
+    __device__ __forceinline__ static float swap32_add(float a, float b) { lane_swap32(a, b); return a + b; }
+    // NS == 4: quarter q of the result = sum over the block's rows of slot q
+    __device__ __forceinline__ float sum(const f32x4& v) const
+    {
+        static_assert(NS == 4 || NS == 2, "");
+        if (NS == 4) return swap32_add(swap16_add(partial(0, v), partial(1, v)), swap16_add(partial(2 % NS, v), partial(3 % NS, v)));
+        const float x = swap16_add(partial(0, v), partial(1, v));       // NS == 2: slots {0,1} in quarters {0,1} and again in {2,3}
+        return swap32_add(x, x);
+    }
+    // NS == 2: quarters {0,1} = slots {0,1} of v0, quarters {2,3} = slots {0,1} of v1
+    __device__ __forceinline__ float sum_pair(const f32x4& v0, const f32x4& v1) const
+    {
+        return swap32_add(swap16_add(partial(0, v0), partial(1, v0)), swap16_add(partial(0, v1), partial(1, v1)));
+    }
+};
 
 // ---- (value, tangent) operand pairs against one weight chunk: every LDS fragment is read once for both products
 template <int NBK, bool FLIP>

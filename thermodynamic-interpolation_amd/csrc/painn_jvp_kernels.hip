@@ -37,12 +37,6 @@
 #ifndef TI_JVP_UPD_OCC
 #define TI_JVP_UPD_OCC 2
 #endif
-#ifndef TI_JVP_RO_OCC
-#define TI_JVP_RO_OCC 1
-#endif
-#ifndef TI_JVP_RO_SC
-#define TI_JVP_RO_SC 2
-#endif
 
 namespace ti {
 
@@ -833,8 +827,11 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? TI_JVP_UPD_OCC : 1)) void painn_jv
 
 // ================================================================================================== tangent readout kernel
 // tout[vnode][c] = (Vr . tv_c) gate + (Vr . v_c) tgate   (LayerReadout.forward, cpainn.py:425-437)
+// The cross-lane sums below are VALU lane swaps (mfma_chain.hpp: xquarters), and that matters here: with ds_bpermute the split
+// build of this kernel lost (Vr . v) sums of whole tiles whenever EXEC was narrowed for the store while the permute was still
+// outstanding.
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, TI_JVP_RO_OCC) void painn_jvp_readout_kernel(const JvpReadoutParams p)
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_readout_kernel(const JvpReadoutParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -844,17 +841,7 @@ __global__ __launch_bounds__(256, TI_JVP_RO_OCC) void painn_jvp_readout_kernel(c
     float* vec = reinterpret_cast<float*>(lds + 4 * CH4);
     for (int i = threadIdx.x; i < RV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-#ifdef TI_JVP_RO_REGPIPE
-    struct {
-        Pipe<NB, T, 1> p;
-        __device__ __forceinline__ void init(const f32x4* s2, int n, f32x4* l, int, int) { p.init(s2, n, l); }
-        __device__ __forceinline__ const f32x4* acquire() { return p.begin(); }
-        __device__ __forceinline__ void release() { p.end(); }
-        __device__ __forceinline__ void drain() {}
-    } pipe;
-#else
-    PipeDMA<NB, T, TI_JVP_RO_SC> pipe;
-#endif
+    PipeDMA<NB, T, 2> pipe;
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
     const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;      // virtual node
@@ -878,20 +865,12 @@ __global__ __launch_bounds__(256, TI_JVP_RO_OCC) void painn_jvp_readout_kernel(c
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = r16::load_block(vec + RV::B0 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B0 * F, 2 * ch + 1, q);
             f32x4 b0 = Z4, b1 = Z4;
-#ifdef TI_JVP_RO_UNPAIRED
-            r16::gemm_bt(a0, a1, ss, wl, lane); r16::gemm_bt(b0, b1, tss, wl, lane);
-#else
             r16::gemm_bt2(a0, a1, b0, b1, ss, tss, wl, lane);
-#endif
             t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
             pipe.release();
         }
     }
-#ifdef TI_JVP_RO_LNSPLIT
-    { A16 nn, kk; r16::ln_silu_stats(t, nn, kk, vec + RV::G0 * F, vec + RV::BE0 * F, q); r16::ln_tangent(u, nn, kk); }
-#else
     r16::ln_silu_dual(t, u, vec + RV::G0 * F, vec + RV::BE0 * F, q);
-#endif
     {
         OP h1, th1;
         h1.set(t); th1.set(u);
@@ -900,20 +879,12 @@ __global__ __launch_bounds__(256, TI_JVP_RO_OCC) void painn_jvp_readout_kernel(c
             const f32x4* wl = pipe.acquire();
             f32x4 a0 = r16::load_block(vec + RV::B1 * F, 2 * ch, q), a1 = r16::load_block(vec + RV::B1 * F, 2 * ch + 1, q);
             f32x4 b0 = Z4, b1 = Z4;
-#ifdef TI_JVP_RO_UNPAIRED
-            r16::gemm_bt(a0, a1, h1, wl, lane); r16::gemm_bt(b0, b1, th1, wl, lane);
-#else
             r16::gemm_bt2(a0, a1, b0, b1, h1, th1, wl, lane);
-#endif
             t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1; u.b[2 * ch] = b0; u.b[2 * ch + 1] = b1;
             pipe.release();
         }
     }
-#ifdef TI_JVP_RO_LNSPLIT
-    { A16 nn, kk; r16::ln_silu_stats(t, nn, kk, vec + RV::G1 * F, vec + RV::BE1 * F, q); r16::ln_tangent(u, nn, kk); }
-#else
     r16::ln_silu_dual(t, u, vec + RV::G1 * F, vec + RV::BE1 * F, q);
-#endif
     float gate = 0.f, tgate = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
@@ -926,9 +897,6 @@ __global__ __launch_bounds__(256, TI_JVP_RO_OCC) void painn_jvp_readout_kernel(c
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float acc = 0.f, tacc = 0.f;
-#ifdef TI_JVP_RO_FENCE
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) {
             const f32x4 w = r16::load_block(vec + RV::VR * F, nb, q);
@@ -936,13 +904,7 @@ __global__ __launch_bounds__(256, TI_JVP_RO_OCC) void painn_jvp_readout_kernel(c
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc = fmaf(vv[r], w[r], acc); tacc = fmaf(tv[r], w[r], tacc); }
         }
-#ifdef TI_JVP_RO_FENCE2
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         acc = r16::xquarters(acc); tacc = r16::xquarters(tacc);
-#ifdef TI_JVP_RO_FENCE2
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         if (ok && q == 0) p.tout[nd * 3 + c] = tacc * gate + acc * tgate;
     }
     pipe.drain();
@@ -964,12 +926,6 @@ __global__ void painn_div_reduce_kernel(const float* __restrict__ tout, long lon
 static size_t jvp_edge_lds(int NB) { return 4 * (size_t)256 * NB * 16 + 4 * 128 * 4 + EV::COUNT * (size_t)32 * NB * 4; }
 static size_t jvp_node_lds(int NB, int count)
 {
-#ifdef TI_JVP_RO_BIGLDS
-    if (count == RV::COUNT) return 100 * 1024;
-#endif
-#ifdef TI_JVP_RO_PADLDS
-    if (count == RV::COUNT) return 4 * (size_t)256 * NB * 16 + (size_t)count * 32 * NB * 4 + TI_JVP_RO_PADLDS;
-#endif
     return 4 * (size_t)256 * NB * 16 + (size_t)count * 32 * NB * 4;
 }
 

@@ -126,7 +126,7 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 // kernel at B >= 32k.  Small launches keep 4 waves: fatter workgroups cost the latency regime 20-60 %.  F = 256 needs the
 // 512-register budget of one wave per SIMD and is always 4 waves.
 __host__ __device__ constexpr int edge_superchunk(int NB, int WAVES) { return (WAVES == 8 && NB == 4) ? 4 : 2; }
-template <int NBK, bool FIRST, bool LAST, bool SPLIT, int WAVES>
+template <int NBK, bool FIRST, bool LAST, bool SPLIT, int WAVES, int NS>
 __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? TI_EDGE_OCC * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = 256 * NB;
@@ -237,19 +237,18 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? TI_EDGE_OCC * 4 / WAVES : 1
         uint32_t mi[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) mi[r] = rows[blk * 16 + 4 * q + r];
-        // Per-atom sums over the block's rows as a 16x16 selection product on the matrix core:
-        //   S[slot][n] = sum_row Sel[slot][row] * val[row][n],  Sel[slot][row] = 1 if the row's destination is that slot.
-        // val is already in B-operand layout (lane (n, q) holds rows 4q + r); Sel in A-operand layout is sel[r] below.  The
-        // products are exact (x 1.0 or x 0.0) and the MFMA sums k in a fixed order, so the result is deterministic.  The
-        // output lands as lane (n, q), register r = slot 4q + r; sn[r] is that slot's atom (or -1).
-        f32x4 sel;
-        int snode[4];
+        // Per-atom sums over the block's rows, in registers (r16::QuarterSum, mfma_chain.hpp): the template builder gives a block
+        // at most 4 destination atoms ("slots", NS = 2 when no block of the template has more than 2); msk[k][r] selects the rows
+        // 4q + r of slot k, and after the lane-row exchanges quarter q of the wave holds the sum of ONE slot, so one atomic
+        // instruction carries the sums of every slot of the block.  qnode is the atom this quarter adds to (or -1).
+        r16::QuarterSum<NS> qs;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sel[r] = (row_slot(mi[r]) == j) ? 1.0f : 0.0f;
-            const int sn = slotnode[blk * 16 + 4 * q + r];
+        for (int r = 0; r < 4; ++r) qs.set_row(r, row_slot(mi[r]));
+        int qnode;
+        {
+            const int sn = slotnode[blk * 16 + r16::QuarterSum<NS>::slot_of_quarter(q)];
             const long long m2 = mg * p.G + (sn >> 8);
-            snode[r] = (sn >= 0 && group_ok && m2 < p.B) ? (int)(m2 * p.A + (sn & 255)) : -1;
+            qnode = (sn >= 0 && group_ok && m2 < p.B) ? (int)(m2 * p.A + (sn & 255)) : -1;
         }
 
         // (phi_c + b) * (w_c + b) for output chunk c (0 gates, 1 scale_edge_dir, 2 ds, 3 de, 4 cross gates), 32 features
@@ -269,10 +268,13 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? TI_EDGE_OCC * 4 / WAVES : 1
         };
         // add the per-slot sums of (v0 | v1) into dst[node*stride + {0,16}] (dst already offset to component / feature)
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
-            const f32x4 s0 = r16::select_sum<SPLIT>(sel, v0), s1 = r16::select_sum<SPLIT>(sel, v1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (snode[r] >= 0) { float* d = dst + (size_t)snode[r] * stride; add_noret(d, s0[r]); add_noret(d + 16, s1[r]); }
+            if (NS == 2) {
+                const float z = qs.sum_pair(v0, v1);                 // quarter q: slot q & 1 of (q >> 1 ? v1 : v0)
+                if (qnode >= 0) add_noret(dst + (size_t)qnode * stride + 16 * (q >> 1), z);
+            } else {
+                const float z0 = qs.sum(v0), z1 = qs.sum(v1);        // quarter q: slot q
+                if (qnode >= 0) { float* d = dst + (size_t)qnode * stride; add_noret(d, z0); add_noret(d + 16, z1); }
+            }
         };
 
 #pragma unroll 1
@@ -608,19 +610,19 @@ static size_t edge_lds_bytes(int NB, int WAVES) { return 2 * edge_superchunk(NB,
 
 static size_t update_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 10 * (size_t)32 * NB * 4; }
 
-template <int NB, int EW>
+template <int NB, int EW, int NS>
 static hipError_t configure_edge()
 {
     const size_t be = edge_lds_bytes(NB, EW);
     hipError_t e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, false, EW>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, false, EW>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, false, EW>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, false, EW>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, true, EW>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, true, EW>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, true, EW>, be)) != hipSuccess) return e;
-    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, true, EW>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, false, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, false, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, false, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, false, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, false, true, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, false, true, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, false, true, true, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds(painn_edge_kernel<2 * NB, true, true, true, EW, NS>, be)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -631,8 +633,9 @@ static hipError_t configure_nb()
     hipError_t e;
 #define TI_SET(k) if ((e = set_lds(k, b)) != hipSuccess) return e
     TI_SET((painn_embed_kernel<NB, WAVES, 2>)); TI_SET((painn_embed_kernel<NB, WAVES, 3>)); TI_SET((painn_embed_kernel<NB, WAVES, 4>));
-    if ((e = configure_edge<NB, 4>()) != hipSuccess) return e;
-    if constexpr (NB <= 4) { if ((e = configure_edge<NB, 8>()) != hipSuccess) return e; }
+    if ((e = configure_edge<NB, 4, 2>()) != hipSuccess) return e;
+    if ((e = configure_edge<NB, 4, 4>()) != hipSuccess) return e;
+    if constexpr (NB <= 4) { if ((e = configure_edge<NB, 8, 2>()) != hipSuccess) return e; }
     const size_t bu = update_lds_bytes(NB);
     if ((e = set_lds(painn_update_kernel<2 * NB, true, false>, bu)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, false, false>, bu)) != hipSuccess) return e;
@@ -680,32 +683,34 @@ hipError_t launch_embed(int NBv, int nseg, const EmbedParams& p, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int NB, int EW>
+template <int NB, int EW, int NS>
 static void launch_edge_w(bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
 {
     const dim3 g((unsigned)((p.n_groups + EW - 1) / EW)), t(64 * EW);          // one wave (= one group or part) each
     const size_t l = edge_lds_bytes(NB, EW);
     if (split) {
-        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true, EW>), g, t, l, st, p);
-        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true, EW>), g, t, l, st, p);
-        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true, EW>), g, t, l, st, p);
-        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true, EW>), g, t, l, st, p);
+        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true, EW, NS>), g, t, l, st, p);
+        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true, EW, NS>), g, t, l, st, p);
+        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true, EW, NS>), g, t, l, st, p);
+        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true, EW, NS>), g, t, l, st, p);
     } else {
-        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false, EW>), g, t, l, st, p);
-        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false, EW>), g, t, l, st, p);
-        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false, EW>), g, t, l, st, p);
-        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false, EW>), g, t, l, st, p);
+        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false, EW, NS>), g, t, l, st, p);
+        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false, EW, NS>), g, t, l, st, p);
+        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false, EW, NS>), g, t, l, st, p);
+        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false, EW, NS>), g, t, l, st, p);
     }
 }
 
 hipError_t launch_edge(int NBv, bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
 {
+    if (p.max_slots > 4) return hipErrorInvalidValue;          // build_templates never produces such a block
     // split-fp16 path only: the f32 path is matrix-bound and loses 4 % to the wider barriers (74.2 -> 77.2 ms per launch)
-    const bool wide = split && p.n_groups >= 2048;          // enough groups to fill every CU with 8-wave workgroups
+    const bool wide = split && p.n_groups >= 2048 && p.max_slots <= 2;          // enough groups to fill every CU with 8-wave workgroups
     TI_DISPATCH_NB(NBv, {
         (void)WAVES;
-        if (NB <= 4 && wide) launch_edge_w<NB, (NB <= 4 ? 8 : 4)>(first, last, split, p, st);
-        else launch_edge_w<NB, 4>(first, last, split, p, st);
+        if (NB <= 4 && wide) launch_edge_w<NB, (NB <= 4 ? 8 : 4), 2>(first, last, split, p, st);
+        else if (p.max_slots <= 2) launch_edge_w<NB, 4, 2>(first, last, split, p, st);
+        else launch_edge_w<NB, 4, 4>(first, last, split, p, st);
     });
     return hipGetLastError();
 }

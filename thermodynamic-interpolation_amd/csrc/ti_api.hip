@@ -122,10 +122,11 @@ struct ti_handle {
     struct Tpl {
         int G = 1, P = 1, nblk = 0;
         DevBuf<uint32_t> rows; DevBuf<int32_t> slotnode;
-        std::vector<int> part_of, part_start;     // per sorted edge: its part; per part: first sorted edge
+        std::vector<int> part_of, part_start, part_len;     // per sorted edge: its part; per part: first sorted edge, edges
+        std::vector<int> pos;                     // row of (molecule-in-group m, sorted edge k) inside its part: pos[m * part_len + (k - part_start)]
+        int max_slots = 0;                        // most destination atoms in any row block (<= EDGE_MAX_SLOTS)
     } tpl[2];
-    int n_tpl = 1, active = 0, parts = 1;
-    bool jvp_ro_split = false;
+    int n_tpl = 1, active = 0, parts = 1, max_slots = 0;
     struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
     DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
@@ -176,25 +177,47 @@ struct Timed {           // RAII: brackets a launch with HIP events when profili
 void set_device(const ti_handle* h) { HIP_CHECK(hipSetDevice(h->device)); }
 
 // ------------------------------------------------------------------------------------------------ painn create
-// rows of `count` molecules' edges whose destination atom lies in [a0, a1), padded to whole 16-row blocks
-static void fill_part(const ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype, int count, int k0, int k1, int nblk,
-                      uint32_t* rw, int32_t* sn)
+// Packs the rows of `count` molecules' edges with sorted position in [k0, k1) into 16-row blocks: rows keep their (molecule, dst,
+// src) order; a block takes at most EDGE_MAX_SLOTS destination atoms (a further one starts the next block, the rest is padding).
+// pos[m * (k1 - k0) + (k - k0)] = row of that edge inside the part; returns the number of blocks used.
+static int pack_part(const ti_handle* h, const int32_t* dst, int count, int k0, int k1, std::vector<int>& pos)
 {
     constexpr int RB = ti::EDGE_ROWS_PER_BLOCK;
-    const int per = k1 - k0, rows = count * per;
-    for (int i = 0; i < nblk * RB; ++i) { rw[i] = (uint32_t)63 << 18; sn[i] = -1; }
-    for (int blk = 0; blk < nblk; ++blk) {
-        int nslot = 0, last_key = -1;
-        for (int j = 0; j < RB; ++j) {
-            const int r = blk * RB + j;
-            if (r >= rows) break;
-            const int m = r / per, k = h->perm[k0 + r % per];
-            const int key = m * 256 + dst[k];
-            if (key != last_key) { sn[(size_t)blk * RB + nslot] = (m << 8) | dst[k]; ++nslot; last_key = key; }
-            rw[r] = 1u | ((uint32_t)m << 1) | ((uint32_t)src[k] << 6) | ((uint32_t)dst[k] << 11) | ((uint32_t)etype[k] << 16) |
-                    ((uint32_t)(nslot - 1) << 18);
+    const int per = k1 - k0;
+    pos.assign((size_t)count * per, 0);
+    int row = 0, nslot = 0, last_key = -1;
+    for (int m = 0; m < count; ++m)
+        for (int k = k0; k < k1; ++k) {
+            const int key = m * 256 + dst[h->perm[k]];
+            if (row % RB == 0) { nslot = 0; last_key = -1; }
+            if (key != last_key) {
+                if (nslot == ti::EDGE_MAX_SLOTS) { row = (row + RB - 1) / RB * RB; nslot = 0; }
+                ++nslot; last_key = key;
+            }
+            pos[(size_t)m * per + (k - k0)] = row++;
         }
-    }
+    return (row + RB - 1) / RB;
+}
+
+// row / slot words of a packed part (ti_internal.hpp); returns the most slots any block holds
+static int fill_part(const ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype, int count, int k0, int k1, int nblk,
+                     const std::vector<int>& pos, uint32_t* rw, int32_t* sn)
+{
+    constexpr int RB = ti::EDGE_ROWS_PER_BLOCK;
+    const int per = k1 - k0;
+    for (int i = 0; i < nblk * RB; ++i) { rw[i] = (uint32_t)63 << 18; sn[i] = -1; }
+    std::vector<int> nslot(std::max(nblk, 1), 0), last_key(std::max(nblk, 1), -1);
+    int most = 0;
+    for (int m = 0; m < count; ++m)
+        for (int kk = 0; kk < per; ++kk) {
+            const int r = pos[(size_t)m * per + kk], blk = r / RB, k = h->perm[k0 + kk];
+            const int key = m * 256 + dst[k];
+            if (key != last_key[blk]) { sn[(size_t)blk * RB + nslot[blk]] = (m << 8) | dst[k]; ++nslot[blk]; last_key[blk] = key; }
+            most = std::max(most, nslot[blk]);
+            rw[r] = 1u | ((uint32_t)m << 1) | ((uint32_t)src[k] << 6) | ((uint32_t)dst[k] << 11) | ((uint32_t)etype[k] << 16) |
+                    ((uint32_t)(nslot[blk] - 1) << 18);
+        }
+    return most;
 }
 
 void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype)
@@ -209,18 +232,20 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
     // ---- throughput template: smallest G in 1..8 whose padding waste is <= 2 %, else the least wasteful
     {
         int bestG = 1; double bestW = 2.0;
+        std::vector<int> pos;
         for (int G = 1; G <= 8 && E > 0; ++G) {
-            const int rows = G * E, padded = (rows + RB - 1) / RB * RB;
+            const int rows = G * E, padded = pack_part(h, dst, G, 0, E, pos) * RB;
             const double waste = double(padded - rows) / padded;
             if (waste < bestW - 1e-12) { bestW = waste; bestG = G; }
             if (waste <= 0.02) { bestG = G; break; }
         }
         if (const char* fg = std::getenv("TI_FORCE_G")) bestG = std::max(1, std::min(8, std::atoi(fg)));      // experiments only
         ti_handle::Tpl& T = h->tpl[0];
-        T.G = bestG; T.P = 1; T.nblk = (bestG * E + RB - 1) / RB;
-        T.part_of.assign(E, 0); T.part_start.assign(1, 0);
+        T.G = bestG; T.P = 1;
+        T.nblk = E > 0 ? pack_part(h, dst, bestG, 0, E, T.pos) : 0;
+        T.part_of.assign(E, 0); T.part_start.assign(1, 0); T.part_len.assign(1, E);
         std::vector<uint32_t> rw((size_t)std::max(T.nblk, 1) * RB); std::vector<int32_t> sn(rw.size());
-        fill_part(h, src, dst, etype, bestG, 0, E, T.nblk, rw.data(), sn.data());
+        T.max_slots = fill_part(h, src, dst, etype, bestG, 0, E, T.nblk, T.pos, rw.data(), sn.data());
         if (T.nblk == 0) { rw[0] = (uint32_t)63 << 18; sn[0] = -1; }
         T.rows.upload(rw); T.slotnode.upload(sn);
     }
@@ -231,7 +256,8 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
         std::vector<int> first_of(A + 1, E);           // first sorted edge with destination >= a
         for (int k = E - 1; k >= 0; --k) first_of[dst[h->perm[k]]] = k;
         for (int a = A - 1; a >= 0; --a) first_of[a] = std::min(first_of[a], first_of[a + 1]);
-        int bestP = 1, best_nblk = (E + RB - 1) / RB; std::vector<int> best_cut{0, E};
+        std::vector<int> pos;
+        int bestP = 1, best_nblk = pack_part(h, dst, 1, 0, E, pos); std::vector<int> best_cut{0, E};
         for (int P = 2; P <= 8; ++P) {
             std::vector<int> cut{0};
             for (int q = 1; q < P; ++q) {             // atom boundary closest to q/P of the rows
@@ -244,19 +270,23 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
             if (cut.empty() || cut.back() >= E) continue;
             cut.push_back(E);
             int nblk = 0;
-            for (int q = 0; q < P; ++q) nblk = std::max(nblk, (cut[q + 1] - cut[q] + RB - 1) / RB);
+            for (int q = 0; q < P; ++q) nblk = std::max(nblk, pack_part(h, dst, 1, cut[q], cut[q + 1], pos));
             if (double(P * nblk * RB - E) / (P * nblk * RB) <= 0.15) { bestP = P; best_nblk = nblk; best_cut = cut; }
         }
         if (bestP * h->tpl[0].G > 1) {
             ti_handle::Tpl& T = h->tpl[1];
-            T.G = 1; T.P = bestP; T.nblk = best_nblk;
+            T.G = 1; T.P = bestP; T.nblk = best_nblk; T.max_slots = 0;
             T.part_start.assign(best_cut.begin(), best_cut.end() - 1);
-            T.part_of.resize(E);
+            T.part_of.resize(E); T.part_len.resize(bestP); T.pos.assign(E, 0);
             for (int q = 0; q < bestP; ++q) for (int k = best_cut[q]; k < best_cut[q + 1]; ++k) T.part_of[k] = q;
             std::vector<uint32_t> rw((size_t)bestP * best_nblk * RB); std::vector<int32_t> sn(rw.size());
-            for (int q = 0; q < bestP; ++q)
-                fill_part(h, src, dst, etype, 1, best_cut[q], best_cut[q + 1], best_nblk, rw.data() + (size_t)q * best_nblk * RB,
-                          sn.data() + (size_t)q * best_nblk * RB);
+            for (int q = 0; q < bestP; ++q) {
+                T.part_len[q] = best_cut[q + 1] - best_cut[q];
+                pack_part(h, dst, 1, best_cut[q], best_cut[q + 1], pos);
+                std::copy(pos.begin(), pos.end(), T.pos.begin() + best_cut[q]);
+                T.max_slots = std::max(T.max_slots, fill_part(h, src, dst, etype, 1, best_cut[q], best_cut[q + 1], best_nblk, pos,
+                                                              rw.data() + (size_t)q * best_nblk * RB, sn.data() + (size_t)q * best_nblk * RB));
+            }
             T.rows.upload(rw); T.slotnode.upload(sn);
             h->n_tpl = 2;
         }
@@ -275,13 +305,15 @@ void select_template(ti_handle* h, long long B)
     }
     const ti_handle::Tpl& T = h->tpl[pick];
     h->active = pick; h->G = T.G; h->parts = T.P; h->nblk = T.nblk; h->rows.p = T.rows.p; h->slotnode.p = T.slotnode.p;
+    h->max_slots = T.max_slots;
 }
 
 // row of (molecule m, sorted edge k) in the e / te layout of the active template
 size_t edge_row_of(const ti_handle* h, size_t m, size_t k)
 {
     const ti_handle::Tpl& T = h->tpl[h->active];
-    const size_t part = T.part_of[k], r = (m % T.G) * (T.P == 1 ? (size_t)h->d.n_edges : 0) + (k - T.part_start[part]);
+    // throughput template: one part, pos over (molecule in group, sorted edge); latency template: G = 1, pos over the sorted edge
+    const size_t part = T.part_of[k], r = T.pos[(m % T.G) * (size_t)h->d.n_edges + k];
     return ((m / T.G) * T.P + part) * T.nblk * ti::EDGE_ROWS_PER_BLOCK + r;
 }
 
@@ -378,16 +410,11 @@ void pack_painn(ti_handle* h, const float* wts)
     o = begin_stream();
     layer(h->readout.W0, F, F, 0); layer(h->readout.W1, F, F, 0);
     h->st_readout = end_stream(o);
-    // tangent readout kernel: 16-row chunk format, always f32 operands.  Its split-fp16 build returned sporadically wrong
-    // (Vr . v) sums for whole 16-node tiles whenever two of its workgroups shared a CU (1 tile in ~2 000; never with one
-    // workgroup per CU, never in the f32 build; LDS-DMA, barriers and waits were ruled out -- DESIGN.md 3.5); the kernel is
-    // 0.5 % of a divergence evaluation, so it simply stays on the f32 path.
+    // tangent readout kernel: 16-row chunk format
     o = begin_stream();
-    h->jvp_ro_split = split && std::getenv("TI_JVP_RO_SPLIT") != nullptr;          // diagnosis only (tools/diag_race.py)
     for (size_t Wm : {h->readout.W0, h->readout.W1})
         for (int nbo = 0; nbo < NB; ++nbo) {
-            if (h->jvp_ro_split) pack_chunk16_split(pk, wts + Wm, F, F, 32 * nbo, 0, NBK);
-            else pack_chunk16(pk, wts + Wm, F, F, 32 * nbo, 0, NBK);
+            chunk16(Wm, F, F, 32 * nbo, 0);
         }
     pad_even(o);
     h->st_jvp_readout = end_stream(o);
@@ -543,7 +570,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             EdgeParams p{};
             p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
             p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p; p.nslots = nullptr;
-            p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
+            p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.max_slots = h->max_slots; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
             p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
             HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, h->d.precision == TI_PREC_F16X2, p, st));
@@ -580,7 +607,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         p.stream = h->S(h->st_jvp_readout); p.nch = h->st_jvp_readout.nch; p.vecs = h->jvp_ro_vecs.p; p.b2_gate = h->b2_gate;
         p.N = VN; p.B = B; p.A = A; p.D = jr->D; p.G = h->G; p.s = h->s.p; p.v = h->v.p; p.ts = h->ts.p; p.tv = h->tv.p; p.tout = jr->tout;
         Timed tm(h, TI_KERNEL_PAINN_JVP_READOUT);
-        HIP_CHECK(launch_jvp_readout(NB, h->jvp_ro_split, p, st));        // f32 operands unless TI_JVP_RO_SPLIT (see pack_painn)
+        HIP_CHECK(launch_jvp_readout(NB, split, p, st));
     }
     {
         ReadoutParams p{};

@@ -18,11 +18,14 @@ namespace ti {
 // (molecule group, part):  gi = mg * parts + part;  rows / slotnode hold [parts][nblk*16] entries.
 // The E_m edges of one molecule are sorted by (dst, src); G molecules form a "group" whose G*E_m edge rows are padded
 // to NBLK blocks of EDGE_ROWS_PER_BLOCK rows.  One wave owns one group, so every per-atom sum over incoming edges stays inside a wave
-// in that wave's program order (deterministic).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots".
+// in that wave's program order (deterministic).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots";
+// a block holds at most EDGE_MAX_SLOTS of them (a fifth destination atom starts the next block, the rest of the block is
+// padding), so the per-slot sums of a block fit the four lane rows of a wave (mfma_chain.hpp: r16::QuarterSum).
 //   row word : bit0 valid | mol_local<<1 (5b) | src<<6 (5b) | dst<<11 (5b) | etype<<16 (2b) | slot<<18 (6b, 63 = none)
 //   slot word: mol_local<<8 | atom     (-1 = unused)
 constexpr int ROW_VALID = 1;
 constexpr int EDGE_ROWS_PER_BLOCK = 16;     // painn_edge_kernel walks a group in 16-row blocks (16x16x4 MFMA)
+constexpr int EDGE_MAX_SLOTS = 4;
 __host__ __device__ inline int row_mol(uint32_t w) { return (w >> 1) & 31; }
 __host__ __device__ inline int row_src(uint32_t w) { return (w >> 6) & 31; }
 __host__ __device__ inline int row_dst(uint32_t w) { return (w >> 11) & 31; }
@@ -39,6 +42,7 @@ struct EdgeParams {
     const float* edge_emb;                  // [4][F]  (first layer: e = edge_emb[type])
     const uint32_t* rows; const int32_t* slotnode; const int32_t* nslots;
     int nblk, G, parts, A;                  // parts per group (see above); n_groups counts parts
+    int max_slots;                          // most destination atoms any row block of the template holds (<= 4)
     long long B, n_groups;
     float length_scale;
     const float* x;                         // [B*A][3]
