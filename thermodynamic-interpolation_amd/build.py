@@ -9,8 +9,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libti_hip.so")
-SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
-HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
+SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_nb2.hip", "painn_edge_nb4.hip", "painn_edge_nb8.hip",
+           "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
+HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", "painn_edge_kernel.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -28,7 +29,7 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, jobs: int = 4, verbose: bool = False) -> str:
+def build(force: bool = False, jobs: int = 8, verbose: bool = False) -> str:
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     if not force and not _stale(SO, deps):
         return SO

@@ -176,9 +176,7 @@ struct PipeDMA {
         }
         if (++sub == SC) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef TI_ABL_NOBARRIER         // ablation build (timing only, racy): no workgroup barrier at the superchunk boundary
             __syncthreads();
-#endif
             idx = (idx + 1 == nsup) ? 0 : idx + 1;
             par ^= 1; sub = 0;
         }
@@ -622,49 +620,49 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
     }
 };
 
-// chunk image: [(blk*(NBK/2) + m)*2 + {0: hi, 1: lo}][lane] of 16-byte h8.  One output block at a time keeps only two
-// accumulators and two weight fragments live (the matrix pipe is no longer the bottleneck in this mode).
+// chunk image: [(blk*(NBK/2) + m)*2 + {0: hi, 1: lo}][lane] of 16-byte h8, i.e. 2*KS "steps" of two fragments each, contiguous.
+// One step = 3 MFMAs (48 matrix cycles) on one (hi, lo) weight fragment pair.  The fragments of step s + TI_FRAG_AHEAD are read
+// from LDS before the MFMAs of step s issue; the scheduling barriers pin that order (hipcc otherwise sinks each read to just
+// in front of its own MFMAs and waits lgkmcnt(0) there: the wave then sits through a full LDS latency every 48 matrix
+// cycles).  The barrier mask lets VALU / SALU / VMEM instructions cross, DS reads and MFMAs not.
+#ifndef TI_FRAG_AHEAD
+#define TI_FRAG_AHEAD 1
+#endif
 template <int NBK, bool FLIP>
-__device__ __forceinline__ void gemm_split_block(f32x4& acc, const Opnd<NBK, true>& in, const h8* wl, int lane)
+__device__ __forceinline__ void gemm_split_chunk(f32x4& acc0, f32x4& acc1, const Opnd<NBK, true>& in, const h8* wl, int lane)
 {
-    constexpr int KS = NBK / 2;
-    f32x4 x = {0, 0, 0, 0};
-#ifdef TI_ABL_NOWLO            // ablation build (timing only, wrong results): half the LDS fragment reads, same matrix work
-    h8 wh = wl[lane], wlo = wh;
-#else
-    h8 wh = wl[lane], wlo = wl[64 + lane];
-#endif
+    constexpr int KS = NBK / 2, STEPS = 2 * KS, AH = TI_FRAG_AHEAD < STEPS ? TI_FRAG_AHEAD : STEPS;
+    f32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+    h8 fh[AH + 1], fl[AH + 1];                       // ring of fragment pairs, statically indexed after unrolling
 #pragma unroll
-    for (int m = 0; m < KS; ++m) {
-        // fragment of the next k-step is read ahead; the compiler barrier keeps hipcc from hoisting ALL reads (64 VGPRs)
-        const int nx = m + 1 < KS ? m + 1 : m;
-#ifdef TI_ABL_NOWLO
-        const h8 nh = wl[(nx * 2 + 0) * 64 + lane], nl = nh;
-#else
-        const h8 nh = wl[(nx * 2 + 0) * 64 + lane], nl = wl[(nx * 2 + 1) * 64 + lane];
-#endif
-#ifndef TI_NO_LDS_FENCE
-        asm volatile("" ::: "memory");
-#endif
+    for (int s = 0; s < AH; ++s) { fh[s] = wl[(2 * s) * 64 + lane]; fl[s] = wl[(2 * s + 1) * 64 + lane]; }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + AH < STEPS) {
+            fh[(s + AH) % (AH + 1)] = wl[(2 * (s + AH)) * 64 + lane];
+            fl[(s + AH) % (AH + 1)] = wl[(2 * (s + AH) + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0x16);
+        const h8 wh = fh[s % (AH + 1)], wlo = fl[s % (AH + 1)];
+        const int m = s % KS;
+        f32x4& acc = s < KS ? acc0 : acc1;
+        f32x4& x = s < KS ? x0 : x1;
         if (FLIP) { acc = mfma16h(in.hi[m], wh, acc); x = mfma16h(in.lo[m], wh, x); x = mfma16h(in.hi[m], wlo, x); }
         else      { acc = mfma16h(wh, in.hi[m], acc); x = mfma16h(wh, in.lo[m], x); x = mfma16h(wlo, in.hi[m], x); }
-        wh = nh; wlo = nl;
+        __builtin_amdgcn_sched_barrier(0x16);
     }
-    acc += x * 4.8828125e-4f;                                            // 2^-11
+    acc0 += x0 * 4.8828125e-4f;                                          // 2^-11
+    acc1 += x1 * 4.8828125e-4f;
 }
 template <int NBK>
 __device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd<NBK, true>& in, const f32x4* wl4, int lane)
 {
-    const h8* wl = reinterpret_cast<const h8*>(wl4);
-    gemm_split_block<NBK, false>(acc0, in, wl, lane);
-    gemm_split_block<NBK, false>(acc1, in, wl + NBK * 64, lane);
+    gemm_split_chunk<NBK, false>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane);
 }
 template <int NBK>
 __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK, true>& in, const f32x4* wl4, int lane)
 {
-    const h8* wl = reinterpret_cast<const h8*>(wl4);
-    gemm_split_block<NBK, true>(acc0, in, wl, lane);
-    gemm_split_block<NBK, true>(acc1, in, wl + NBK * 64, lane);
+    gemm_split_chunk<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane);
 }
 // fp32 operands through the same interface
 template <int NBK>

@@ -1,0 +1,7 @@
+// painn_edge_nb4.hip -- edge-kernel instantiations for n_features = 128 (painn_edge_kernel.hpp)
+#include "painn_edge_kernel.hpp"
+
+namespace ti {
+hipError_t configure_edge_nb4() { return configure_edge_nb<4>(); }
+hipError_t launch_edge_nb4(bool first, bool last, bool split, const EdgeParams& p, hipStream_t st) { return launch_edge_nb<4>(first, last, split, p, st); }
+}  // namespace ti

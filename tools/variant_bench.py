@@ -20,7 +20,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "thermodynamic-interpolation_amd")
 VDIR = os.path.join(PKG, "build", "variants")
-SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
+SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_nb2.hip", "painn_edge_nb4.hip", "painn_edge_nb8.hip",
+           "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
 
 
 def lib_of(tag):
@@ -45,7 +46,7 @@ def build(specs):
             csrc = os.environ.get("TI_VARIANT_SRC") or os.path.join(PKG, "csrc")       # e.g. an extracted `git archive` of another commit
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c", os.path.join(csrc, src), "-o", obj])
             return obj
-        with ThreadPoolExecutor(max_workers=5) as ex:
+        with ThreadPoolExecutor(max_workers=8) as ex:
             objs = list(ex.map(one, SOURCES))
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_of(tag), *objs])
         print("built", lib_of(tag), flush=True)
