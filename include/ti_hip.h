@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TI_ABI_VERSION 2
+#define TI_ABI_VERSION 3
 
 enum { TI_OK = 0, TI_E_ARG = -1, TI_E_HIP = -2, TI_E_NAN = -3, TI_E_ALLOC = -4, TI_E_UNSUPPORTED = -5 };
 enum { TI_MEM_HOST = 0, TI_MEM_DEVICE = 1 };
@@ -109,6 +109,9 @@ typedef struct ti_rollout_desc {
     int64_t traj_offset;    /* global index of trajectory 0 of this call (multi-GPU shards keep RNG independent of the split) */
     const float* t_grid;    /* [n_step] host memory */
     float   rtol, atol;     /* DOPRI5 tolerances (> 0); ignored by the fixed-grid schemes */
+    int64_t step_offset;    /* EM: index of this call's first step in the noise counter (step k of the call draws with counter
+                               step_offset + k), so that a trajectory continued by a second call does not reuse the first call's
+                               noise; 0 for a rollout that starts at the beginning */
 } ti_rollout_desc;
 
 /* number of path rows ti_*_rollout writes for (n_step, save_every) */
@@ -165,9 +168,23 @@ int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* desc, const floa
 
 /* ---- shared ------------------------------------------------------------------------------------------------------ */
 void ti_destroy(ti_handle* h);
-/* Run on an external HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream); NULL restores the
- * handle's own stream. */
-int ti_set_stream(ti_handle* h, void* hip_stream);
+/* Streams.  A handle enqueues all device work on ONE stream: its own (created non-blocking at create()) or, with
+ * ti_set_stream(h, s, TI_STREAM_EXTERNAL), the caller's hipStream_t `s` -- where s == NULL then means the legacy null stream
+ * (torch's default stream reports cuda_stream == 0).  TI_STREAM_OWN restores the handle's own stream (`s` is ignored).
+ * TI_MEM_DEVICE inputs written by work on ANOTHER stream (a torch kernel that produced x0 / cond) are ordered with
+ * ti_wait_stream(h, producer): the handle's stream then waits for everything enqueued on `producer` so far (NULL = the null
+ * stream).  Every call returns after synchronising the handle's stream, so outputs need no further ordering. */
+enum { TI_STREAM_OWN = 0, TI_STREAM_EXTERNAL = 1 };
+int ti_set_stream(ti_handle* h, void* hip_stream, int mode);
+int ti_wait_stream(ti_handle* h, void* producer_stream);
+/* Pin the edge-row layout of a painn handle: TI_TEMPLATE_AUTO (from the batch size of each call, the default),
+ * TI_TEMPLATE_THROUGHPUT or TI_TEMPLATE_LATENCY.  Results are bit-identical within one layout and agree to fp32 round-off
+ * across them, so a run sharded over ranks pins the layout it would use for the GLOBAL batch and becomes independent of
+ * the rank count.  (The TI_TEMPLATE environment variable, read per call, overrides this.) */
+enum { TI_TEMPLATE_AUTO = -1, TI_TEMPLATE_THROUGHPUT = 0, TI_TEMPLATE_LATENCY = 1 };
+int ti_painn_set_template(ti_handle* h, int which);
+/* the layout ti_painn_* would choose for a batch of B molecules (TI_TEMPLATE_THROUGHPUT / _LATENCY) */
+int ti_painn_template_for(ti_handle* h, int64_t B);
 /* Pre-size the HBM workspace for batches up to B trajectories (otherwise grown on demand). */
 int ti_reserve(ti_handle* h, int64_t B);
 /* Live kernel timing with HIP events on the handle's stream (bench.py roofline leg). */

@@ -1,0 +1,217 @@
+"""Boundary behaviour of the engines on the GPU: stream ordering against torch producers, device-resident mirrors, the EM
+noise counter across chained calls, layout pinning for sharded runs (two real engines sharing one GPU), device selection."""
+import importlib
+import os
+import socket
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, pkg, rel_l2
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def small_engine(precision="f32", A=9, F=32, L=2, device=0):
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    tpl = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 3), W.painn_param_spec(W.AMBIENT, F, L, 25))
+    return ti.engine.PainnEngine(W.AMBIENT, F, L, A, *tpl, np.arange(A), flat, temp_length=100.0, precision=precision, device=device), tpl
+
+
+def test_inputs_from_a_running_torch_kernel_are_ordered():
+    """x0 is produced by work still running on torch's current stream when the engine is called (MEM_DEVICE inputs
+    were read on the handle's own stream with no ordering).  The result must equal the one from synchronised inputs."""
+    ti = pkg()
+    eng, _ = small_engine()
+    A, B = 9, 4096
+    dev = torch.device("cuda:0")
+    base = torch.from_numpy(ti.synthetic.molecule_coords(B, A, seed=1)).to(dev)
+    cond = torch.from_numpy(ti.synthetic.ambient_cond(B, A)).to(dev)
+    torch.cuda.synchronize()
+    want = eng.drift(base * 1.5, 0.4, cond).cpu().numpy()
+    big = torch.randn(6144, 6144, device=dev)
+    for _ in range(3):
+        torch.cuda.synchronize()
+        junk = big
+        for _ in range(12):                      # ~tens of ms of queued matmuls in front of the producer of x
+            junk = junk @ big * 1e-3
+        x = base * 1.5 + 0.0 * junk[0, 0]        # enqueued behind them on torch's stream; not finished when drift() is entered
+        got = eng.drift(x, 0.4, cond)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                # same on a non-default torch stream
+        junk = big
+        for _ in range(12):
+            junk = junk @ big * 1e-3
+        x = base * 1.5 + 0.0 * junk[0, 0]
+        got = eng.drift(x, 0.4, cond)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_external_and_null_stream_modes():
+    ti = pkg()
+    eng, _ = small_engine()
+    x = ti.synthetic.molecule_coords(64, 9, seed=2); cond = ti.synthetic.ambient_cond(64, 9)
+    want = eng.drift(x, 0.1, cond)
+    eng.set_stream(0, external=True)             # the legacy null stream (what torch.cuda.default_stream reports)
+    np.testing.assert_array_equal(eng.drift(x, 0.1, cond), want)
+    s = torch.cuda.Stream()
+    eng.set_stream(s.cuda_stream, external=True)
+    np.testing.assert_array_equal(eng.drift(x, 0.1, cond), want)
+    eng.set_stream(None, external=False)         # back on the handle's own stream
+    np.testing.assert_array_equal(eng.drift(x, 0.1, cond), want)
+
+
+def test_tensors_of_another_device_or_dtype_are_refused():
+    ti = pkg()
+    eng, _ = small_engine()
+    x = torch.zeros(4, 9, 3, device="cuda:0")
+    cond = torch.zeros(4, 9, 2, device="cuda:0")
+    with pytest.raises(TypeError):
+        eng.drift(x.double(), 0.0, cond)
+    with pytest.raises(ValueError):
+        eng.drift(x, 0.0, cond[:, :, :1].contiguous())           # cond must be [B, A, 2]
+    with pytest.raises(ValueError):
+        eng.drift(x, 0.0, cond.cpu())                            # mixed memory spaces
+    with pytest.raises(TypeError):
+        eng.drift(x.cpu().numpy(), 0.0, cond.cpu().numpy(), out=np.zeros((4, 9, 3), np.float64))      # would be filled in a temporary
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(ValueError):
+            eng.drift(x.to("cuda:1"), 0.0, cond.to("cuda:1"))
+
+
+def _golden_batch(g, atom_key, device):
+    from test_gpu_api import golden_batch
+    b = golden_batch(g, atom_key)
+    for k, v in list(vars(b).items()):
+        if isinstance(v, torch.Tensor):
+            setattr(b, k, v.to(device))
+    return b
+
+
+def test_mirror_classes_stay_on_the_gpu(monkeypatch):
+    """MoleculeIntegrator / cPaiNN with a CUDA batch: coordinates go in through data_ptr() and the path comes back as a CUDA
+    tensor, bit-identical to the host path; no float tensor of x0's size is copied to the host on the way."""
+    from test_gpu_api import golden_batch, state_dict_of
+    ti = pkg()
+    g = load_golden("ambient_small")
+    b = ti.thermo.ambient.cPaiNN(n_features=int(g["F"]), score_layers=int(g["L"]), temp_length=int(g["temp_length"]))
+    b.load_state_dict(state_dict_of(g)); b.eval(); b.to(torch.device("cuda:0"))
+    n_step = 5
+    integ = ti.thermo.ambient.MoleculeIntegrator(b=b, method="heun", n_step=n_step)
+    host = golden_batch(g, "atoms")
+    xts_h, _, nfe_h, _ = integ.rollout(host)
+    dev = _golden_batch(g, "atoms", "cuda:0")
+    C = ti.thermo._common
+    real = C.to_numpy
+    copied = []
+
+    def spy(x, dtype=None):
+        if C.is_torch(x) and x.is_cuda and x.is_floating_point() and x.numel() >= dev.x0.numel():
+            copied.append(tuple(x.shape))
+        return real(x, dtype)
+    monkeypatch.setattr(C, "to_numpy", spy)
+    xts_d, dlogp_d, nfe_d, bidx = integ.rollout(dev)
+    assert xts_d.is_cuda and dlogp_d.is_cuda and nfe_d == nfe_h and bidx is dev.batch
+    assert not copied, f"coordinate-sized tensors went through the host: {copied}"
+    np.testing.assert_array_equal(xts_d.cpu().numpy(), xts_h.numpy())
+    dev.t = 0.25 * torch.ones_like(dev.atoms)
+    host.t = 0.25 * torch.ones_like(host.atoms)
+    out_d = b(dev).output
+    assert out_d.is_cuda and not copied
+    np.testing.assert_array_equal(out_d.cpu().numpy(), b(host).output.numpy())
+
+
+def test_em_step_offset_continues_the_noise_stream():
+    """K steps in one call == the same K steps cut into two calls when the second passes step_offset (the noise
+    counter used to restart at 0 in every call, so chained calls reused their noise)."""
+    ti = pkg()
+    eng, _ = small_engine()
+    x0 = ti.synthetic.molecule_coords(32, 9, seed=5); cond = ti.synthetic.ambient_cond(32, 9)
+    grid = ti.engine.time_grid(0.0, 1.0, 9)
+    kw = dict(scheme="em", eps=0.05, seed=11, save_every=0)
+    whole, _ = eng.rollout(x0, cond, grid, **kw)
+    a, _ = eng.rollout(x0, cond, grid[:5], **kw)
+    b, _ = eng.rollout(a[0], cond, grid[4:], step_offset=4, **kw)
+    np.testing.assert_array_equal(b, whole)
+    c, _ = eng.rollout(a[0], cond, grid[4:], **kw)                # without the offset the second half reuses steps 0..3
+    assert np.abs(c - whole).max() > 1e-4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _shard_worker(rank, world, port, n_total, q):
+    import torch as th
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    ti = importlib.import_module("thermodynamic-interpolation_amd")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # rehearsal: both ranks share cuda:0, gather on host copies
+    try:
+        syn, W = ti.synthetic, ti.weights
+        A, F, L = 18, 32, 2
+        tpl = syn.fully_connected_template(A)
+        flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 3), W.painn_param_spec(W.AMBIENT, F, L, 25))
+        eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *tpl, np.arange(A), flat, temp_length=100.0, precision="f16x2")
+        ti.distributed.pin_template(eng, n_total)
+        x0 = th.from_numpy(syn.molecule_coords(n_total, A, seed=9)); cond = th.from_numpy(syn.ambient_cond(n_total, A))
+        grid = ti.engine.time_grid(0.0, 1.0, 4)
+
+        def roll(xl, cl, off):
+            out, _ = eng.rollout(xl.numpy(), cl.numpy(), grid, scheme="em", eps=0.02, seed=7, traj_offset=off, save_every=0)
+            return th.from_numpy(out[0])
+        full = ti.distributed.rollout_sharded(roll, x0, cond)
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_run_equals_single_process_bit_for_bit():
+    """The real engine under the sharded driver, two ranks on one GPU: the gathered end states equal a single-process run of the
+    whole batch bit for bit.  The batch (2100) is cut so that the shards alone would pick the latency layout while the global
+    batch picks the throughput one: pin_template makes both ranks use the global choice."""
+    import torch.multiprocessing as mp
+    ti = pkg()
+    n_total, world = 2100, 2
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    [p.start() for p in procs]
+    outs = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    syn, W = ti.synthetic, ti.weights
+    A, F, L = 18, 32, 2
+    tpl = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 3), W.painn_param_spec(W.AMBIENT, F, L, 25))
+    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *tpl, np.arange(A), flat, temp_length=100.0, precision="f16x2")
+    assert eng.template_for(n_total) == "throughput" and eng.template_for(n_total // 2) == "latency"
+    want, _ = eng.rollout(syn.molecule_coords(n_total, A, seed=9), syn.ambient_cond(n_total, A), ti.engine.time_grid(0.0, 1.0, 4), scheme="em",
+                          eps=0.02, seed=7, save_every=0)
+    for r in range(world):
+        np.testing.assert_array_equal(outs[r], want[0])
+
+
+def test_engine_on_the_highest_device_index():
+    """device > 0 (never exercised on the one-GPU boxes of round 1): create on the last visible GPU and compare with device 0."""
+    ti = pkg()
+    n = ti._lib.lib().ti_device_count()
+    if n < 2:
+        pytest.skip("one visible GPU")
+    e0, _ = small_engine(device=0)
+    e1, _ = small_engine(device=n - 1)
+    x = ti.synthetic.molecule_coords(128, 9, seed=4); cond = ti.synthetic.ambient_cond(128, 9)
+    np.testing.assert_array_equal(e1.drift(x, 0.3, cond), e0.drift(x, 0.3, cond))
+    xd = torch.from_numpy(x).to(f"cuda:{n - 1}"); cd = torch.from_numpy(cond).to(f"cuda:{n - 1}")
+    got = e1.drift(xd, 0.3, cd)
+    assert got.device.index == n - 1
+    np.testing.assert_array_equal(got.cpu().numpy(), e0.drift(x, 0.3, cond))

@@ -132,3 +132,37 @@ def test_synthetic_weights_are_reproducible_and_nontrivial():
     assert all(np.array_equal(a[k], b[k]) for k in a) and any(not np.array_equal(a[k], c[k]) for k in a)
     g = a["net.7.mlp.mlp.1.weight"]
     assert abs(g.mean() - 1) < 0.1 and g.std() > 0.01       # LayerNorm gamma is perturbed away from 1
+
+
+def test_as_ptr_refuses_what_the_kernels_would_misread():
+    """The kernels read / write float32 C-contiguous memory of the documented shape: other dtypes are refused instead of being
+    reinterpreted, and a numpy `out` that would need a copy is refused instead of filling a temporary."""
+    ti = pkg()
+    A = ti._lib.as_ptr
+    x = np.zeros((4, 3, 3), np.float64)
+    p, keep, dev, idx = A(x, shape=(4, 3, 3))                       # inputs are converted (a copy is fine for an input)
+    assert keep.dtype == np.float32 and not dev and idx is None
+    with pytest.raises(ValueError):
+        A(np.zeros((4, 3, 2), np.float32), shape=(4, 3, 3), what="x")
+    with pytest.raises(TypeError):
+        A(np.zeros((4, 3, 3), np.float64), shape=(4, 3, 3), out=True)
+    with pytest.raises(TypeError):
+        A(np.zeros((4, 3, 6), np.float32)[:, :, ::2], shape=(4, 3, 3), out=True)          # not contiguous: would be copied
+    ok = np.zeros((4, 3, 3), np.float32)
+    assert A(ok, shape=(4, 3, 3), out=True)[1] is ok
+    torch = pytest.importorskip("torch")
+    with pytest.raises(TypeError):
+        A(torch.zeros(4, 3, 3, dtype=torch.float64))
+    with pytest.raises(TypeError):
+        A(torch.zeros(4, 3, 3, dtype=torch.float16))
+    with pytest.raises(ValueError):
+        A(torch.zeros(4, 3, 6)[:, :, ::2])
+    with pytest.raises(ValueError):
+        A(torch.zeros(4, 3, 3), shape=(4, 3, 2))
+    assert A(torch.zeros(4, 3, 3), shape=(4, 3, 3))[2] is False
+
+
+def test_rollout_desc_carries_the_noise_counter_offset():
+    ti = pkg()
+    rd = ti.engine._rollout_desc("em", np.linspace(0, 1, 5), 0, 0, 0.1, 3, 100, False, step_offset=40)
+    assert rd.step_offset == 40 and rd.n_step == 5 and rd.traj_offset == 100

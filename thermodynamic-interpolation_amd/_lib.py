@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "ti_rollout_rows", "ti_version", "ti_device_count", "ti_last_error",
     "ti_adw_create", "ti_adw_drift", "ti_adw_drift_div", "ti_adw_rollout", "ti_adw_rollout_dlogp",
     "ti_painn_create", "ti_painn_drift", "ti_painn_rollout", "ti_painn_drift_jvp", "ti_painn_drift_div", "ti_painn_rollout_dlogp",
-    "ti_destroy", "ti_set_stream", "ti_reserve", "ti_profile_enable", "ti_profile_read",
+    "ti_destroy", "ti_set_stream", "ti_wait_stream", "ti_painn_set_template", "ti_painn_template_for", "ti_reserve", "ti_profile_enable", "ti_profile_read",
     "ti_painn_debug_tap", "ti_painn_debug_read", "ti_selftest",
 ]
 
@@ -45,7 +45,7 @@ class AdwDesc(C.Structure):
 class RolloutDesc(C.Structure):
     _fields_ = [("scheme", C.c_int32), ("n_step", C.c_int32), ("save_every", C.c_int32), ("mem", C.c_int32),
                 ("eps", C.c_float), ("com_free_noise", C.c_int32), ("seed", C.c_uint64), ("traj_offset", C.c_int64),
-                ("t_grid", C.POINTER(C.c_float)), ("rtol", C.c_float), ("atol", C.c_float)]
+                ("t_grid", C.POINTER(C.c_float)), ("rtol", C.c_float), ("atol", C.c_float), ("step_offset", C.c_int64)]
 
 
 class TiError(RuntimeError):
@@ -103,7 +103,10 @@ def lib():
     L.ti_adw_rollout_dlogp.argtypes = [vp, C.POINTER(RolloutDesc), vp, vp, vp, C.c_int64, vp, vp, C.POINTER(C.c_int64)]
     L.ti_destroy.argtypes = [vp]
     L.ti_destroy.restype = None
-    L.ti_set_stream.argtypes = [vp, vp]
+    L.ti_set_stream.argtypes = [vp, vp, C.c_int]
+    L.ti_wait_stream.argtypes = [vp, vp]
+    L.ti_painn_set_template.argtypes = [vp, C.c_int]
+    L.ti_painn_template_for.argtypes = [vp, C.c_int64]
     L.ti_reserve.argtypes = [vp, C.c_int64]
     L.ti_profile_enable.argtypes = [vp, C.c_int]
     L.ti_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -131,15 +134,29 @@ def iptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
-def as_ptr(buf):
-    """(void* , keepalive, is_device) for a numpy array (host), a torch tensor (cpu or cuda) or a raw int device address."""
+def as_ptr(buf, *, shape=None, out=False, what="buffer"):
+    """(void*, keepalive, is_device, device_index) for a numpy array (host), a torch tensor (cpu or cuda) or a raw int device
+    address.  The kernels read and write float32, C-contiguous memory of exactly the documented shape, so anything else is
+    refused here instead of being reinterpreted (tensors) or silently copied (a numpy `out` the caller would never see filled)."""
     if buf is None:
-        return None, None, False
+        return None, None, False, None
     if isinstance(buf, int):
-        return C.c_void_p(buf), None, True
+        return C.c_void_p(buf), None, True, None
     if hasattr(buf, "data_ptr"):                      # torch.Tensor without importing torch
+        if str(buf.dtype) != "torch.float32":
+            raise TypeError(f"{what} must be float32, got {buf.dtype}")
         if not buf.is_contiguous():
-            raise ValueError("tensor must be contiguous")
-        return C.c_void_p(buf.data_ptr()), buf, bool(buf.is_cuda)
-    a = np.ascontiguousarray(buf, dtype=np.float32)
-    return C.c_void_p(a.ctypes.data), a, False
+            raise ValueError(f"{what} must be contiguous")
+        if shape is not None and tuple(buf.shape) != tuple(shape):
+            raise ValueError(f"{what} must have shape {tuple(shape)}, got {tuple(buf.shape)}")
+        dev = bool(buf.is_cuda)
+        return C.c_void_p(buf.data_ptr()), buf, dev, (buf.device.index if dev else None)
+    if out:
+        if not isinstance(buf, np.ndarray) or buf.dtype != np.float32 or not buf.flags["C_CONTIGUOUS"] or not buf.flags["WRITEABLE"]:
+            raise TypeError(f"{what} must be a writable C-contiguous float32 numpy array (or a torch tensor); it is filled in place")
+        a = buf
+    else:
+        a = np.ascontiguousarray(buf, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{what} must have shape {tuple(shape)}, got {tuple(a.shape)}")
+    return C.c_void_p(a.ctypes.data), a, False, None

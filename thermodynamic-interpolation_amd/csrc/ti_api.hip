@@ -103,6 +103,7 @@ struct ti_handle {
     int kind = 0;                 // 0 painn, 1 adw
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t wait_ev = nullptr;          // ti_wait_stream
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[TI_KERNEL_COUNT];
@@ -126,7 +127,7 @@ struct ti_handle {
         std::vector<int> pos;                     // row of (molecule-in-group m, sorted edge k) inside its part: pos[m * part_len + (k - part_start)]
         int max_slots = 0;                        // most destination atoms in any row block (<= EDGE_MAX_SLOTS)
     } tpl[2];
-    int n_tpl = 1, active = 0, parts = 1, max_slots = 0;
+    int n_tpl = 1, active = 0, parts = 1, max_slots = 0, pinned_tpl = TI_TEMPLATE_AUTO;
     struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
     DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
@@ -149,6 +150,7 @@ struct ti_handle {
     ~ti_handle()
     {
         for (auto& v2 : ev) for (auto& pr : v2) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        if (wait_ev) (void)hipEventDestroy(wait_ev);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
     const float* F(size_t off) const { return flat.p + off; }
@@ -295,14 +297,21 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
 
 // Template for a call over B molecules: the latency template while the throughput one would leave SIMDs without a wave
 // (fewer groups than the 1024 SIMDs of the chip); TI_TEMPLATE=throughput|latency pins it (tests, reproducibility across shards).
-void select_template(ti_handle* h, long long B)
+int template_for(const ti_handle* h, long long B)
 {
     int pick = 0;
     if (h->n_tpl > 1) {
         const long long groups0 = (B + h->tpl[0].G - 1) / h->tpl[0].G;
         pick = groups0 < 1024 ? 1 : 0;
+        if (h->pinned_tpl != TI_TEMPLATE_AUTO) pick = h->pinned_tpl;
         if (const char* e = std::getenv("TI_TEMPLATE")) pick = std::strcmp(e, "latency") == 0 ? 1 : std::strcmp(e, "throughput") == 0 ? 0 : pick;
     }
+    return pick;
+}
+
+void select_template(ti_handle* h, long long B)
+{
+    const int pick = template_for(h, B);
     const ti_handle::Tpl& T = h->tpl[pick];
     h->active = pick; h->G = T.G; h->parts = T.P; h->nblk = T.nblk; h->rows.p = T.rows.p; h->slotnode.p = T.slotnode.p;
     h->max_slots = T.max_slots;
@@ -725,7 +734,7 @@ int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1,
             HIP_CHECK(launch_axpy(x, x, dt, b1, (long long)n, st));
             if (aux.dl) HIP_CHECK(launch_axpy(aux.dl, aux.dl, -dt * aux.div_scale, aux.d1, (long long)ndl, st));
             if (rd->scheme == TI_SCHEME_EM && rd->eps > 0.0f)
-                HIP_CHECK(launch_noise(x, std::sqrt(2.0f * rd->eps * std::fabs(dt)), rd->seed, rd->traj_offset, k, B, comps,
+                HIP_CHECK(launch_noise(x, std::sqrt(2.0f * rd->eps * std::fabs(dt)), rd->seed, rd->traj_offset, (int)(rd->step_offset + k), B, comps,
                                        rd->com_free_noise ? atoms_for_com : 0, st));
         }
         const int step = k + 1;
@@ -920,6 +929,7 @@ int check_rollout_desc(const ti_rollout_desc* rd)
                 return fail(TI_E_ARG, "t_grid must be strictly monotonic");
     if (rd->mem != TI_MEM_HOST && rd->mem != TI_MEM_DEVICE) return fail(TI_E_ARG, "unknown mem kind");
     if (rd->eps < 0.f) return fail(TI_E_ARG, "eps must be >= 0");
+    if (rd->step_offset < 0 || rd->step_offset + rd->n_step > 0x7fffffffLL) return fail(TI_E_ARG, "step_offset out of range");
     return TI_OK;
 }
 
@@ -1380,11 +1390,41 @@ void ti_destroy(ti_handle* h)
     delete h;
 }
 
-int ti_set_stream(ti_handle* h, void* hip_stream)
+int ti_set_stream(ti_handle* h, void* hip_stream, int mode)
 {
     if (!h) return fail(TI_E_ARG, "NULL handle");
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    if (mode != TI_STREAM_OWN && mode != TI_STREAM_EXTERNAL) return fail(TI_E_ARG, "unknown stream mode");
+    h->stream = mode == TI_STREAM_EXTERNAL ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
     return TI_OK;
+}
+
+int ti_wait_stream(ti_handle* h, void* producer_stream)
+{
+    if (!h) return fail(TI_E_ARG, "NULL handle");
+    return guarded([&]() -> int {
+        set_device(h);
+        hipStream_t prod = reinterpret_cast<hipStream_t>(producer_stream);
+        if (prod == h->stream) return TI_OK;                     // same stream: already ordered
+        if (!h->wait_ev) HIP_CHECK(hipEventCreateWithFlags(&h->wait_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(h->wait_ev, prod));
+        HIP_CHECK(hipStreamWaitEvent(h->stream, h->wait_ev, 0));
+        return TI_OK;
+    });
+}
+
+int ti_painn_set_template(ti_handle* h, int which)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (which != TI_TEMPLATE_AUTO && which != TI_TEMPLATE_THROUGHPUT && which != TI_TEMPLATE_LATENCY) return fail(TI_E_ARG, "unknown template");
+    if (which == TI_TEMPLATE_LATENCY && h->n_tpl < 2) which = TI_TEMPLATE_THROUGHPUT;      // this species has only one layout
+    h->pinned_tpl = which;
+    return TI_OK;
+}
+
+int ti_painn_template_for(ti_handle* h, int64_t B)
+{
+    if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    return template_for(h, B);
 }
 
 int ti_profile_enable(ti_handle* h, int on)

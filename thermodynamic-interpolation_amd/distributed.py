@@ -3,7 +3,10 @@
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).  The
 reference has no distributed path at all; trajectories never interact (edges never cross molecules), so
 there is no exchange step during integration and none is invented here.  Per-trajectory RNG is keyed by the GLOBAL
-trajectory index (``traj_offset``), so the samples do not depend on the number of ranks.
+trajectory index (``traj_offset``; a trajectory continued by a second call passes ``step_offset``), and ``pin_template`` fixes
+the edge-row layout to the one the GLOBAL batch would get, so fixed-step samples are bit-identical for every rank count
+(the adaptive ``dopri5`` chooses its steps from rank-local error norms, like the reference does per mini-batch: there the
+agreement is to solver tolerance).
 """
 from __future__ import annotations
 
@@ -47,6 +50,14 @@ def gather_trajectories(local, n_total: int, group=None):
     blocks = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(blocks, pad, group=group)
     return torch.cat([blocks[r][: counts[r]] for r in range(world)], dim=0)
+
+
+def pin_template(engine, n_total: int) -> str:
+    """Pin ``engine`` (a PainnEngine) to the edge-row layout a single-process run over all ``n_total`` trajectories would use;
+    call it on every rank before the sharded rollout.  Returns the layout's name."""
+    which = engine.template_for(n_total)
+    engine.set_template(which)
+    return which
 
 
 def rollout_sharded(rollout_fn, x0, cond, group=None):

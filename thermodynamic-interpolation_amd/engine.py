@@ -36,7 +36,7 @@ def _time_grid_numpy(start: float, end: float, n_step: int) -> np.ndarray:
     return np.where(i < n_step // 2, lo, hi).astype(np.float32)
 
 
-def _rollout_desc(scheme, t_grid, save_every, mem, eps, seed, traj_offset, com_free_noise, rtol=0.0, atol=0.0):
+def _rollout_desc(scheme, t_grid, save_every, mem, eps, seed, traj_offset, com_free_noise, rtol=0.0, atol=0.0, step_offset=0):
     t_grid = np.ascontiguousarray(t_grid, np.float32)
     if t_grid.ndim != 1 or t_grid.size < 1:
         raise ValueError("t_grid must be a non-empty 1-D array")
@@ -45,7 +45,7 @@ def _rollout_desc(scheme, t_grid, save_every, mem, eps, seed, traj_offset, com_f
             raise ValueError(f"unknown scheme {scheme!r}; expected one of {sorted(_lib.SCHEMES)}")
         scheme = _lib.SCHEMES[scheme]
     rd = _lib.RolloutDesc(scheme, t_grid.size, int(save_every), mem, float(eps), int(bool(com_free_noise)), int(seed),
-                          int(traj_offset), _lib.fptr(t_grid), float(rtol), float(atol))
+                          int(traj_offset), _lib.fptr(t_grid), float(rtol), float(atol), int(step_offset))
     rd._keep = t_grid
     return rd
 
@@ -59,6 +59,7 @@ def _alloc_like(template, shape):
 
 class _Engine:
     h = None
+    device = 0
 
     def close(self):
         if self.h:
@@ -71,8 +72,37 @@ class _Engine:
         except Exception:
             pass
 
-    def set_stream(self, hip_stream: int | None):
-        _lib.check(_lib.lib().ti_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+    def set_stream(self, hip_stream: int | None, external: bool = True):
+        """Run on the caller's HIP stream (`hip_stream` = hipStream_t as int; 0 / None = the null stream, which is what torch's
+        default stream reports), or with external=False on the handle's own stream again."""
+        _lib.check(_lib.lib().ti_set_stream(self.h, C.c_void_p(hip_stream or 0), 1 if external else 0))
+
+    def wait_stream(self, hip_stream: int | None):
+        """Order the handle's stream after everything enqueued so far on `hip_stream` (0 / None = the null stream)."""
+        _lib.check(_lib.lib().ti_wait_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def _ptrs(self, *specs):
+        """as_ptr over (buffer, shape, is_output, name) specs; all present buffers must live in one memory space.  Device buffers
+        must be on this engine's GPU, and the handle's stream is ordered after torch's current stream on that GPU first, so a
+        tensor produced by a still-running torch kernel is never read early.  Returns (pointers, is_device, keepalives)."""
+        ptrs, keep, spaces, devs = [], [], set(), set()
+        for buf, shape, out, what in specs:
+            pt, k, dev, idx = _lib.as_ptr(buf, shape=shape, out=out, what=what)
+            ptrs.append(pt); keep.append(k)
+            if buf is not None:
+                spaces.add(dev)
+                if idx is not None:
+                    devs.add(idx)
+        if len(spaces) > 1:
+            raise ValueError("all buffers of a call must live in the same memory space (all host or all on the GPU)")
+        dev = bool(spaces and spaces.pop())
+        if dev:
+            if devs - {self.device}:
+                raise ValueError(f"tensors live on cuda:{sorted(devs)} but this engine was created on device {self.device}")
+            if devs:                                  # torch tensors (raw int addresses carry no stream: the caller orders them)
+                import torch
+                self.wait_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        return ptrs, dev, keep
 
     def reserve(self, B: int):
         _lib.check(_lib.lib().ti_reserve(self.h, int(B)))
@@ -109,42 +139,48 @@ class PainnEngine(_Engine):
         if not self.h:
             raise _lib.TiError(-1, _lib.last_error())
 
-    def _bufs(self, x, cond):
-        xp, xk, xdev = _lib.as_ptr(x)
-        cp, ck, cdev = _lib.as_ptr(cond if self.ncond else None)
+    TEMPLATES = {"auto": -1, "throughput": 0, "latency": 1}
+
+    def set_template(self, which: str = "auto"):
+        """Pin the edge-row layout ('throughput' | 'latency') or let each call choose from its batch size ('auto')."""
+        _lib.check(_lib.lib().ti_painn_set_template(self.h, self.TEMPLATES[which]))
+
+    def template_for(self, B: int) -> str:
+        """The layout a call over B molecules would use."""
+        return "latency" if _lib.lib().ti_painn_template_for(self.h, int(B)) == 1 else "throughput"
+
+    def _check_x(self, x, name="x"):
+        if x is None or len(x.shape) != 3 or tuple(x.shape[1:]) != (self.A, 3):
+            raise ValueError(f"{name} must be [B,{self.A},3]")
+        return int(x.shape[0])
+
+    def _cond_spec(self, cond, B):
         if self.ncond and cond is None:
             raise ValueError("this variant needs per-node conditioning (cond)")
-        if self.ncond and cdev != xdev:
-            raise ValueError("x and cond must live in the same memory space")
-        return xp, cp, xdev, (xk, ck)
+        return (cond if self.ncond else None, (B, self.A, self.ncond), False, "cond")
 
     def drift(self, x, t, cond=None, out=None):
         """x [B,A,3] -> drift [B,A,3] at time t."""
-        B = int(x.shape[0])
-        if tuple(x.shape[1:]) != (self.A, 3):
-            raise ValueError(f"x must be [B,{self.A},3]")
-        xp, cp, dev, keep = self._bufs(x, cond)
-        out = _alloc_like(x if dev else None, (B, self.A, 3)) if out is None else out
-        op, _, odev = _lib.as_ptr(out)
-        if odev != dev:
-            raise ValueError("out must live where x lives")
+        B = self._check_x(x)
+        if out is None:
+            out = _alloc_like(x if hasattr(x, "data_ptr") and x.is_cuda else None, (B, self.A, 3))
+        (xp, cp, op), dev, keep = self._ptrs((x, (B, self.A, 3), False, "x"), self._cond_spec(cond, B), (out, (B, self.A, 3), True, "out"))
         _lib.check(_lib.lib().ti_painn_drift(self.h, xp, float(t), cp, B, op, _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
         return out
 
     def rollout(self, x0, cond, t_grid, scheme="euler", save_every=1, eps=0.0, seed=0, traj_offset=0, com_free_noise=False, out=None,
-                rtol=1e-4, atol=1e-4):
+                rtol=1e-4, atol=1e-4, step_offset=0):
         """Returns (path [rows,B,A,3], n_fevals).  scheme: 'euler' | 'heun' | 'em' | 'midpoint' | 'rk4' on the grid, or 'dopri5'
-        (adaptive, tolerances rtol / atol; the grid then only selects the output times)."""
-        B = int(x0.shape[0])
-        if tuple(x0.shape[1:]) != (self.A, 3):
-            raise ValueError(f"x0 must be [B,{self.A},3]")
-        xp, cp, dev, keep = self._bufs(x0, cond)
-        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, eps, seed, traj_offset, com_free_noise, rtol, atol)
+        (adaptive, tolerances rtol / atol; the grid then only selects the output times).  step_offset: EM noise counter of the
+        call's first step (pass the number of steps already taken when continuing a trajectory)."""
+        B = self._check_x(x0, "x0")
+        on_gpu = hasattr(x0, "data_ptr") and x0.is_cuda
+        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if on_gpu else _lib.MEM_HOST, eps, seed, traj_offset, com_free_noise,
+                           rtol, atol, step_offset)
         rows = int(_lib.lib().ti_rollout_rows(rd.n_step, rd.save_every))
-        out = _alloc_like(x0 if dev else None, (rows, B, self.A, 3)) if out is None else out
-        op, _, odev = _lib.as_ptr(out)
-        if odev != dev:
-            raise ValueError("out must live where x0 lives")
+        if out is None:
+            out = _alloc_like(x0 if on_gpu else None, (rows, B, self.A, 3))
+        (xp, cp, op), dev, keep = self._ptrs((x0, (B, self.A, 3), False, "x0"), self._cond_spec(cond, B), (out, (rows, B, self.A, 3), True, "out"))
         nfe = C.c_int64(0)
         _lib.check(_lib.lib().ti_painn_rollout(self.h, C.byref(rd), xp, cp, B, op, C.byref(nfe)))
         return out, nfe.value
@@ -152,43 +188,36 @@ class PainnEngine(_Engine):
     # ---- forward-mode derivative, exact divergence, dlogp
     def jvp(self, x, xdot, t, cond=None):
         """(b(x), (d b / d x) xdot), both [B,A,3]."""
-        B = int(x.shape[0])
-        if tuple(x.shape[1:]) != (self.A, 3) or tuple(xdot.shape) != tuple(x.shape):
-            raise ValueError(f"x and xdot must be [B,{self.A},3]")
-        xp, cp, dev, keep = self._bufs(x, cond)
-        tp, tk, tdev = _lib.as_ptr(xdot)
-        if tdev != dev:
-            raise ValueError("xdot must live where x lives")
-        out, tan = _alloc_like(x if dev else None, (B, self.A, 3)), _alloc_like(x if dev else None, (B, self.A, 3))
-        _lib.check(_lib.lib().ti_painn_drift_jvp(self.h, xp, tp, float(t), cp, B, _lib.as_ptr(out)[0], _lib.as_ptr(tan)[0],
-                                                 _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+        B = self._check_x(x)
+        like = x if hasattr(x, "data_ptr") and x.is_cuda else None
+        out, tan = _alloc_like(like, (B, self.A, 3)), _alloc_like(like, (B, self.A, 3))
+        (xp, tp, cp, op, tnp), dev, keep = self._ptrs((x, (B, self.A, 3), False, "x"), (xdot, (B, self.A, 3), False, "xdot"), self._cond_spec(cond, B),
+                                                      (out, None, True, "out"), (tan, None, True, "out_tan"))
+        _lib.check(_lib.lib().ti_painn_drift_jvp(self.h, xp, tp, float(t), cp, B, op, tnp, _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
         return out, tan
 
     def drift_div(self, x, t, cond=None):
         """(b(x) [B,A,3], div [B]) with div = sum_ij d b_ij / d x_ij -- the reference's compute_divergence without its 1e-2."""
-        B = int(x.shape[0])
-        if tuple(x.shape[1:]) != (self.A, 3):
-            raise ValueError(f"x must be [B,{self.A},3]")
-        xp, cp, dev, keep = self._bufs(x, cond)
-        out, div = _alloc_like(x if dev else None, (B, self.A, 3)), _alloc_like(x if dev else None, (B,))
-        _lib.check(_lib.lib().ti_painn_drift_div(self.h, xp, float(t), cp, B, _lib.as_ptr(out)[0], _lib.as_ptr(div)[0],
-                                                 _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+        B = self._check_x(x)
+        like = x if hasattr(x, "data_ptr") and x.is_cuda else None
+        out, div = _alloc_like(like, (B, self.A, 3)), _alloc_like(like, (B,))
+        (xp, cp, op, dp), dev, keep = self._ptrs((x, (B, self.A, 3), False, "x"), self._cond_spec(cond, B), (out, None, True, "out"), (div, None, True, "out_div"))
+        _lib.check(_lib.lib().ti_painn_drift_div(self.h, xp, float(t), cp, B, op, dp, _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
         return out, div
 
     def rollout_dlogp(self, x0, cond, t_grid, scheme="euler", save_every=1, div_scale=1.0, out_scale=1.0, reverse_ode=False,
                       rtol=1e-4, atol=1e-4):
         """Two-state rollout (x, dlogp): returns (path [rows,B,A,3], dlogp [rows,B], n_fevals).  d(dlogp)/dt = -div_scale * div
         (reverse_ode: (-b, +div_scale * div) on the descending grid the caller passes), dlogp is written * out_scale."""
-        B = int(x0.shape[0])
-        if tuple(x0.shape[1:]) != (self.A, 3):
-            raise ValueError(f"x0 must be [B,{self.A},3]")
-        xp, cp, dev, keep = self._bufs(x0, cond)
-        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, 0.0, 0, 0, False, rtol, atol)
+        B = self._check_x(x0, "x0")
+        on_gpu = hasattr(x0, "data_ptr") and x0.is_cuda
+        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if on_gpu else _lib.MEM_HOST, 0.0, 0, 0, False, rtol, atol)
         rows = int(_lib.lib().ti_rollout_rows(rd.n_step, rd.save_every))
-        out, dl = _alloc_like(x0 if dev else None, (rows, B, self.A, 3)), _alloc_like(x0 if dev else None, (rows, B))
+        out, dl = _alloc_like(x0 if on_gpu else None, (rows, B, self.A, 3)), _alloc_like(x0 if on_gpu else None, (rows, B))
+        (xp, cp, op, dp), dev, keep = self._ptrs((x0, (B, self.A, 3), False, "x0"), self._cond_spec(cond, B), (out, None, True, "out"), (dl, None, True, "out_dlogp"))
         nfe = C.c_int64(0)
         _lib.check(_lib.lib().ti_painn_rollout_dlogp(self.h, C.byref(rd), xp, cp, B, float(div_scale), float(out_scale), int(bool(reverse_ode)),
-                                                     _lib.as_ptr(out)[0], _lib.as_ptr(dl)[0], C.byref(nfe)))
+                                                     op, dp, C.byref(nfe)))
         return out, dl, nfe.value
 
     # ---- parity-test taps
@@ -217,45 +246,39 @@ class AdwEngine(_Engine):
         if not self.h:
             raise _lib.TiError(-1, _lib.last_error())
 
-    @staticmethod
-    def _same_space(*bufs):
-        flags = {bool(_lib.as_ptr(b)[2]) for b in bufs}
-        if len(flags) != 1:
-            raise ValueError("x, beta0 and beta1 must live in the same memory space")
-        return flags.pop()
-
     def drift(self, x, t, beta0, beta1, out=None, return_div=False):
         """b(x, t) [B]; with return_div also d b / d x (the 1-D divergence, reference scaling NOT applied)."""
         B = int(x.shape[0])
-        dev = self._same_space(x, beta0, beta1)
-        (xp, xk, _), (b0p, b0k, _), (b1p, b1k, _) = _lib.as_ptr(x), _lib.as_ptr(beta0), _lib.as_ptr(beta1)
-        out = _alloc_like(x if dev else None, (B,)) if out is None else out
-        op, _, _ = _lib.as_ptr(out)
+        like = x if hasattr(x, "data_ptr") and x.is_cuda else None
+        if out is None:
+            out = _alloc_like(like, (B,))
+        div = _alloc_like(like, (B,)) if return_div else None
+        (xp, b0p, b1p, op, dp), dev, keep = self._ptrs((x, (B,), False, "x"), (beta0, (B,), False, "beta0"), (beta1, (B,), False, "beta1"),
+                                                       (out, (B,), True, "out"), (div, None, True, "out_div"))
         mem = _lib.MEM_DEVICE if dev else _lib.MEM_HOST
         if not return_div:
             _lib.check(_lib.lib().ti_adw_drift(self.h, xp, float(t), b0p, b1p, B, op, mem))
             return out
-        div = _alloc_like(x if dev else None, (B,))
-        dp, _, _ = _lib.as_ptr(div)
         _lib.check(_lib.lib().ti_adw_drift_div(self.h, xp, float(t), b0p, b1p, B, op, dp, mem))
         return out, div
 
     def rollout(self, x0, beta0, beta1, t_grid, scheme="euler", save_every=1, eps=0.0, seed=0, traj_offset=0, out=None,
-                return_dlogp=False, rtol=1e-4, atol=1e-4):
+                return_dlogp=False, rtol=1e-4, atol=1e-4, step_offset=0):
         """(path [rows,B], n_fevals), or (path, dlogp [rows,B] (already * 1e2 like the reference), n_fevals)."""
         B = int(x0.shape[0])
-        dev = self._same_space(x0, beta0, beta1)
-        (xp, xk, _), (b0p, b0k, _), (b1p, b1k, _) = _lib.as_ptr(x0), _lib.as_ptr(beta0), _lib.as_ptr(beta1)
-        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if dev else _lib.MEM_HOST, eps, seed, traj_offset, False, rtol, atol)
+        on_gpu = hasattr(x0, "data_ptr") and x0.is_cuda
+        rd = _rollout_desc(scheme, t_grid, save_every, _lib.MEM_DEVICE if on_gpu else _lib.MEM_HOST, eps, seed, traj_offset, False, rtol, atol,
+                           step_offset)
         rows = int(_lib.lib().ti_rollout_rows(rd.n_step, rd.save_every))
-        out = _alloc_like(x0 if dev else None, (rows, B)) if out is None else out
-        op, _, _ = _lib.as_ptr(out)
+        if out is None:
+            out = _alloc_like(x0 if on_gpu else None, (rows, B))
+        dl = _alloc_like(x0 if on_gpu else None, (rows, B)) if return_dlogp else None
+        (xp, b0p, b1p, op, dp), dev, keep = self._ptrs((x0, (B,), False, "x0"), (beta0, (B,), False, "beta0"), (beta1, (B,), False, "beta1"),
+                                                       (out, (rows, B), True, "out"), (dl, None, True, "out_dlogp"))
         nfe = C.c_int64(0)
         if not return_dlogp:
             _lib.check(_lib.lib().ti_adw_rollout(self.h, C.byref(rd), xp, b0p, b1p, B, op, C.byref(nfe)))
             return out, nfe.value
-        dl = _alloc_like(x0 if dev else None, (rows, B))
-        dp, _, _ = _lib.as_ptr(dl)
         _lib.check(_lib.lib().ti_adw_rollout_dlogp(self.h, C.byref(rd), xp, b0p, b1p, B, op, dp, C.byref(nfe)))
         return out, dl, nfe.value
 

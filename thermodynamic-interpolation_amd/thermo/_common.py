@@ -25,6 +25,19 @@ def is_torch(x) -> bool:
     return hasattr(x, "data_ptr") and hasattr(x, "detach")
 
 
+def is_cuda(x) -> bool:
+    return is_torch(x) and bool(x.is_cuda)
+
+
+def as_f32(x, shape):
+    """`x` as a float32, C-contiguous [shape] buffer WHERE IT LIVES: a CUDA tensor stays on the GPU (the engine then uses it
+    in place through data_ptr(), no host copy), anything else becomes a numpy array."""
+    if is_cuda(x):
+        import torch
+        return x.detach().to(torch.float32).reshape(shape).contiguous()
+    return np.ascontiguousarray(to_numpy(x, np.float32).reshape(shape))
+
+
 def to_numpy(x, dtype=None) -> np.ndarray:
     if is_torch(x):
         x = x.detach().cpu().numpy()
@@ -34,6 +47,8 @@ def to_numpy(x, dtype=None) -> np.ndarray:
 
 def like(result: np.ndarray, template):
     """Return `result` in the container type of `template` (torch tensor on the template's device, or numpy)."""
+    if is_torch(result):                          # device-resident path: already a tensor where the inputs live
+        return result
     if is_torch(template):
         import torch
         return torch.from_numpy(np.ascontiguousarray(result)).to(template.device)

@@ -102,9 +102,14 @@ class PaiNNShell:
                                                      temperatures=self.temperatures, device=self._device, precision=self.precision)
         return self._engines[key]
 
-    def cond_of(self, batch, B, A) -> np.ndarray | None:
+    def cond_of(self, batch, B, A, on_gpu=False):
+        """[B, A, n_cond] float32 conditioning; a CUDA tensor when `on_gpu` (the batch lives on the GPU), else numpy."""
         if not self.COND_KEYS:
             return None
+        if on_gpu:
+            import torch
+            cols = [getattr(batch, k).detach().to(torch.float32).reshape(B, A) for k in self.COND_KEYS]
+            return torch.stack(cols, dim=-1).contiguous()
         cols = [C.to_numpy(getattr(batch, k)).astype(np.float32).reshape(B, A) for k in self.COND_KEYS]   # latent T is int64 (mdqm9_latent.py:184)
         return np.ascontiguousarray(np.stack(cols, axis=-1))
 
@@ -114,8 +119,8 @@ class PaiNNShell:
         t = C.to_numpy(batch.t, np.float64).ravel()
         if np.ptp(t) != 0.0:
             raise NotImplementedError("per-molecule times are a training-only input; the sampling path evaluates one t per call")
-        x = np.ascontiguousarray(C.to_numpy(batch.x, np.float32).reshape(B, A, 3))
-        out = self.engine_for(A, src, dst, ety, ids).drift(x, float(t[0]), self.cond_of(batch, B, A))
+        x = C.as_f32(batch.x, (B, A, 3))                  # a CUDA batch is evaluated in place, no host round trip
+        out = self.engine_for(A, src, dst, ety, ids).drift(x, float(t[0]), self.cond_of(batch, B, A, C.is_cuda(x)))
         batch.output = C.like(out.reshape(B * A, 3), batch.x)
         return batch
 
@@ -133,9 +138,9 @@ class ODEWrapperBase:
 
     def _eval(self, batch, x, t, with_div):
         B, A, src, dst, ety, ids = split_batch(batch, self.b.ATOM_KEY)
-        xs = np.ascontiguousarray(C.to_numpy(x, np.float32).reshape(B, A, 3))
+        xs = C.as_f32(x, (B, A, 3))
         eng = self.b.engine_for(A, src, dst, ety, ids)
-        cond = self.b.cond_of(batch, B, A)
+        cond = self.b.cond_of(batch, B, A, C.is_cuda(xs))
         if with_div:
             out, div = eng.drift_div(xs, float(t), cond)
             return out.reshape(B * A, 3), div
@@ -148,7 +153,7 @@ class ODEWrapperBase:
         if self.return_dlogp:
             x, _ = states
             b, div = self._eval(batch, x, t, True)
-            b, d = C.like(b, x), C.like(div * np.float32(self.DIV_SCALE), x)
+            b, d = C.like(b, x), C.like(div * self.DIV_SCALE if C.is_torch(div) else div * np.float32(self.DIV_SCALE), x)
             return (b, -d) if not self.reverse_ode else (-b, d)
         b, _ = self._eval(batch, states, t, False)
         return C.like(b, states)
@@ -159,7 +164,7 @@ class ODEWrapperBase:
     def compute_divergence(cls, b, batch):
         t = float(C.to_numpy(batch.t).reshape(-1)[0])
         _, div = cls(b)._eval(batch, batch.x, t, True)
-        return C.like(div * np.float32(cls.DIV_SCALE), batch.x)
+        return C.like(div * cls.DIV_SCALE if C.is_torch(div) else div * np.float32(cls.DIV_SCALE), batch.x)
 
     @staticmethod
     def reset_batch(batch, x, integration_time):
@@ -193,19 +198,20 @@ class MoleculeIntegratorBase:
 
     def _rollout(self, batch, traj_offset=0):
         B, A, src, dst, ety, ids = split_batch(batch, self.b.ATOM_KEY)
-        x0 = np.ascontiguousarray(C.to_numpy(batch.x0, np.float32).reshape(B, A, 3))
+        x0 = C.as_f32(batch.x0, (B, A, 3))               # CUDA batches stay in HBM: data_ptr() in, CUDA tensors out
+        gpu = C.is_cuda(x0)
         # without dlogp the reference always integrates on linspace(start, end) (integrators.py:54-55), reverse_ode or not
         grid = _engine.time_grid(self.start, self.end, self.n_step)
         eng = self.b.engine_for(A, src, dst, ety, ids)
         if self.return_dlogp:
             if self.reverse_ode:
                 grid = _engine.time_grid(self.end, self.start, self.n_step)
-            path, dl, nfe = eng.rollout_dlogp(x0, self.b.cond_of(batch, B, A), grid, scheme="euler" if self.method == "em" else self.method,
+            path, dl, nfe = eng.rollout_dlogp(x0, self.b.cond_of(batch, B, A, gpu), grid, scheme="euler" if self.method == "em" else self.method,
                                               save_every=self.save_every, div_scale=self.DIV_SCALE, out_scale=self.SCALE_DLOGP,
                                               reverse_ode=self.reverse_ode, rtol=self.rtol, atol=self.atol)
             return C.like(path.reshape(path.shape[0], B * A, 3), batch.x0), C.like(dl, batch.x0), nfe
-        path, nfe = eng.rollout(x0, self.b.cond_of(batch, B, A), grid, scheme=self.method, save_every=self.save_every, eps=self.eps,
+        path, nfe = eng.rollout(x0, self.b.cond_of(batch, B, A, gpu), grid, scheme=self.method, save_every=self.save_every, eps=self.eps,
                                 seed=self.seed, traj_offset=traj_offset, com_free_noise=self.com_free_noise, rtol=self.rtol, atol=self.atol)
         xts = C.like(path.reshape(path.shape[0], B * A, 3), batch.x0)
-        dlogp = C.like(np.zeros(B, np.float32) * self.SCALE_DLOGP, batch.x0)      # reference: zeros(batch_size) (* 1e2 in ambient)
+        dlogp = batch.x0.new_zeros(B) if gpu else C.like(np.zeros(B, np.float32) * self.SCALE_DLOGP, batch.x0)      # reference: zeros(batch_size) (* 1e2 in ambient)
         return xts, dlogp, nfe

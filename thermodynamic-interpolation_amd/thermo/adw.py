@@ -136,14 +136,20 @@ class StandardIntegrator:
         self.eps, self.seed, self.save_every = eps, seed, save_every
 
     def rollout(self, x0s, beta0s, beta1s, traj_offset: int = 0):
-        x0 = C.to_numpy(x0s, np.float32)
-        if x0.ndim != 2 or x0.shape[1] != 1:
+        if len(x0s.shape) != 2 or x0s.shape[1] != 1:
             raise ValueError("x0s must be [batch, 1]")
-        B = x0.shape[0]
-        b0 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta0s, np.float32).reshape(-1), (B,)))
-        b1 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta1s, np.float32).reshape(-1), (B,)))
+        B = int(x0s.shape[0])
+        if C.is_cuda(x0s):                                   # stay in HBM: data_ptr() in, CUDA tensors out
+            import torch
+            x0 = x0s.detach().to(torch.float32).reshape(B).contiguous()
+            b0 = torch.as_tensor(beta0s, device=x0.device).to(torch.float32).reshape(-1).expand(B).contiguous()
+            b1 = torch.as_tensor(beta1s, device=x0.device).to(torch.float32).reshape(-1).expand(B).contiguous()
+        else:
+            x0 = np.ascontiguousarray(C.to_numpy(x0s, np.float32)[:, 0])
+            b0 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta0s, np.float32).reshape(-1), (B,)))
+            b1 = np.ascontiguousarray(np.broadcast_to(C.to_numpy(beta1s, np.float32).reshape(-1), (B,)))
         grid = _engine.time_grid(self.start, self.end, self.n_step)
-        res = self.ode_wrapper.b.engine().rollout(np.ascontiguousarray(x0[:, 0]), b0, b1, grid, scheme=self.method,
+        res = self.ode_wrapper.b.engine().rollout(x0, b0, b1, grid, scheme=self.method,
                                                   save_every=self.save_every, eps=self.eps, seed=self.seed, traj_offset=traj_offset,
                                                   return_dlogp=bool(self.return_dlogp), rtol=self.rtol, atol=self.atol)
         self.n_fevals = res[-1]
