@@ -41,6 +41,8 @@ def golden_weights(g):
     sd = {k[4:]: v for k, v in g.items() if k.startswith("sd::")}
     if not sd:
         sd = ti.synthetic.painn_state_dict(variant, F, L, 25, int(g["seed"]))
+        if "recipe_keys" in g:              # range fixtures: synthetic weights with some tensors rescaled
+            sd = ti.synthetic.scale_state_dict(sd, list(zip([str(k) for k in g["recipe_keys"]], g["recipe_factors"])))
     return ti.weights.flatten_state_dict(sd, spec)
 
 

@@ -190,10 +190,12 @@ def rollout_reference(ode, batch, n_step, scheme):
 
 
 def painn_case(name, variant, F, L, A, B, template, temp_length, temperatures, *, seed, ts=(0.0, 0.25, 1.0),
-               intermediates=False, traj_steps=0, ctor_init=False, sigma=0.3, atom_ids=None):
+               intermediates=False, traj_steps=0, ctor_init=False, sigma=0.3, atom_ids=None, recipe=None, close_pair=None):
     src, dst, etype = template
     atom_ids = np.arange(A, dtype=np.int32) if atom_ids is None else np.asarray(atom_ids, np.int32)
     x = syn.molecule_coords(B, A, seed=seed, sigma=sigma)
+    if close_pair is not None:            # two atoms of every molecule a distance `close_pair` apart (edge length -> 0)
+        x[:, 1] = x[:, 0] + np.asarray([close_pair, 0.0, 0.0], np.float32)
     if variant == W.AMBIENT:
         cond = syn.ambient_cond(B, A)
     elif variant == W.LATENT_MULTI:
@@ -209,7 +211,12 @@ def painn_case(name, variant, F, L, A, B, template, temp_length, temperatures, *
         for k, v in model.state_dict().items():
             out[f"sd::{k}"] = v.numpy().copy()
     else:
-        model = build_model(variant, F, L, temp_length, temperatures, syn.painn_state_dict(variant, F, L, 25, seed))
+        sd = syn.painn_state_dict(variant, F, L, 25, seed)
+        if recipe:                        # weights = synthetic weights with some tensors rescaled (synthetic.scale_state_dict)
+            sd = syn.scale_state_dict(sd, recipe)
+            out["recipe_keys"] = np.asarray([k for k, _ in recipe])
+            out["recipe_factors"] = np.asarray([f for _, f in recipe], np.float64)
+        model = build_model(variant, F, L, temp_length, temperatures, sd)
     ode = (AmbientODE if variant == W.AMBIENT else LatentODE)(model, return_dlogp=False)
     batch = make_batch(variant, x, cond, src, dst, etype, atom_ids)
     for i, t in enumerate(ts):
@@ -345,10 +352,31 @@ def div_cases():
     painn_div_case("div_ambient_full", W.AMBIENT, 128, 5, 18, 1, fc(18), 100, TEMPS, seed=0, traj_steps=2)      # the headline shape
 
 
+def range_cases():
+    """Magnitude edge cases for the operand path of the matrix products: the un-normalised residual streams
+    s, e and |Vv| (cpainn.py:306-308,363-374) driven to 1e3..1e4 and down to 1e-6..1e-9 by rescaled weights, and an edge of
+    length 1e-4.  The intermediates are recorded so the test can assert that the streams really reach those magnitudes."""
+    fc = syn.fully_connected_template
+    big = [("net.2.embedding.weight", 3e3), ("net.7.mlp.mlp.6.weight", 3e3), ("net.7.mlp.mlp.6.bias", 3e3),
+           ("phi.mlp.6.weight", 60.0), ("phi.mlp.6.bias", 60.0), ("w.mlp.6.weight", 60.0), ("w.mlp.6.bias", 60.0)]
+    tiny = [("net.2.embedding.weight", 1e-7), ("net.7.mlp.mlp.6.weight", 1e-7), ("net.7.mlp.mlp.6.bias", 1e-7),
+            ("phi.mlp.6.weight", 1e-4), ("phi.mlp.6.bias", 1e-4), ("w.mlp.6.weight", 1e-4), ("w.mlp.6.bias", 1e-4)]
+    painn_case("range_big", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=21, intermediates=True, recipe=big)
+    painn_case("range_big_f128", W.AMBIENT, 128, 2, 5, 2, fc(5), 100, TEMPS, seed=22, intermediates=True, recipe=big)
+    painn_case("range_tiny", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=23, intermediates=True, recipe=tiny)
+    painn_case("range_tiny_f128", W.AMBIENT, 128, 2, 5, 2, fc(5), 100, TEMPS, seed=24, intermediates=True, recipe=tiny)
+    painn_case("range_close", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=25, intermediates=True, close_pair=1e-4)
+    painn_case("range_latent_big", W.LATENT_MULTI, 32, 2, 6, 2, fc(6), 75, TEMPS, seed=26, sigma=1.0,
+               recipe=[(k.replace("net.7.", "net.6."), f) for k, f in big])
+
+
 TEMPS = [300, 400, 500, 600, 700, 800, 900, 1000]
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "--range-only" in sys.argv:    # only the magnitude edge cases (the other fixtures are unchanged by them)
+        range_cases()
+        sys.exit(0)
     if "--div-only" in sys.argv:      # only the divergence fixtures (the drift fixtures above are unchanged by them)
         div_cases()
         sys.exit(0)
@@ -374,3 +402,4 @@ if __name__ == "__main__":
     adw_case("adw_h256", 256, 5, 64, seed=0)
     adw_case("adw_ctor_h64", 64, 3, 16, seed=1, ctor_init=True)
     div_cases()
+    range_cases()

@@ -386,3 +386,45 @@ def test_wide_workgroups_at_small_feature_widths(F, monkeypatch):
         eng.close()
     per_mol = np.linalg.norm(outs["f16x2"] - outs["f32"], axis=1) / np.linalg.norm(outs["f32"], axis=1)
     assert per_mol.max() < 3e-5
+
+
+RANGE_CASES = ["range_big", "range_big_f128", "range_tiny", "range_tiny_f128", "range_close", "range_latent_big"]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("name", RANGE_CASES)
+def test_magnitude_edge_cases_vs_reference(name, precision):
+    """Reference fixtures whose un-normalised streams (s, e, v, |Vv|: cpainn.py:306-308, 363-374) reach 1e3 .. 1e6 or only
+    1e-7 .. 1e-9, and an edge of length 1e-4.  Both matrix paths must meet the drift bar: the split-fp16 path scales every such
+    operand row by a power of two before the hi/lo split (mfma_chain.hpp: Opnd::set_scaled), so neither the fp16 range
+    (65504) nor its subnormals limit it.  The bar is relative to the reference's own fp32 round-off on these cases."""
+    g = load_golden(name)
+    ti = pkg()
+    if name.startswith("range_big") or name.startswith("range_tiny"):
+        im = {k[4:]: float(np.abs(v).max()) for k, v in g.items() if k.startswith("im::")}
+        if name.startswith("range_big"):
+            assert im["e_msg0"] > 5e3 and im["s_msg0"] > 3e3 and im["v_upd1"] > 1e5          # beyond fp16's 65504 in layer 2
+        else:
+            assert im["e_msg0"] < 1e-6 and im["s_msg0"] < 1e-6 and im["v_msg0"] < 1e-7       # fp16-subnormal territory
+    eng = ti.engine.PainnEngine(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                                g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"],
+                                precision=precision)
+    orc = oracle_from_golden(g)
+    for i, t in enumerate(g["ts"]):
+        got = eng.drift(g["x"], float(t), g["cond"])
+        assert np.isfinite(got).all(), (name, precision)
+        err = rel_l2(got, g[f"drift_{i}"])
+        exact = orc.drift(g["x"], float(t), g["cond"], precision=64)
+        floor = rel_l2(g[f"drift_{i}"], exact)             # the reference's own distance to exact arithmetic
+        assert err < max(DRIFT_TOL, 3 * floor), (name, precision, i, err, floor)
+
+
+def test_f16x2_refuses_weights_beyond_the_fp16_range():
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    flat = W.flatten_state_dict(syn.painn_state_dict(0, 32, 1, 25, 0), W.painn_param_spec(0, 32, 1, 25)).copy()
+    flat[100] = 1e5
+    with pytest.raises(ti._lib.TiError) as ei:
+        ti.engine.PainnEngine(0, 32, 1, 4, *syn.fully_connected_template(4), np.arange(4), flat, precision="f16x2")
+    assert "65504" in str(ei.value)
+    ti.engine.PainnEngine(0, 32, 1, 4, *syn.fully_connected_template(4), np.arange(4), flat, precision="f32").close()

@@ -593,10 +593,24 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma16h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// exact reciprocal of a power of two (the row scales of Opnd::set_scaled)
+__device__ __forceinline__ float pow2_inverse(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
+
+// max over the 4 lane rows (quarters) that share an edge / node row, in every lane
+__device__ __forceinline__ float xquarters_max(float v)
+{
+    float a = v, b = v;
+    lane_swap16(a, b);
+    a = fmaxf(a, b); b = a;
+    lane_swap32(a, b);
+    return fmaxf(a, b);
+}
+
 template <int NBK, bool SPLIT>
 struct Opnd {                                   // fp32 operand: the activation set itself
     Act<NBK> a;
     __device__ __forceinline__ void set(const Act<NBK>& x) { a = x; }
+    __device__ __forceinline__ float set_scaled(const Act<NBK>& x) { a = x; return 1.0f; }
 };
 template <int NBK>
 struct Opnd<NBK, true> {                        // split operand: hi and scaled-lo halves, NBK/2 k-steps
@@ -617,6 +631,36 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
                 hi[m][i] = h;
                 lo[m][i] = (_Float16)((v - (float)h) * 2048.0f);
             }
+    }
+    // For operand sets that are NOT the output of a LayerNorm (the residual streams e, s, v, |Vv|: any magnitude fp32 holds):
+    // the row (this lane's 16*NBK values and those of the 3 lanes that share its row) is divided by 2^k, k = exponent of the
+    // row's largest |value|, before the split -- exact, and the halves then sit in [2^-24, 2) whatever the row's scale -- and
+    // 2^k is returned; the caller multiplies the product of this operand by it (gemm_*_scaled), again exactly.  Without it a
+    // value >= 65504 overflows the hi half (inf -> NaN downstream) and rows of magnitude < 1e-7 lose their lo half to fp16
+    // subnormals (tests/golden/range_*.npz).
+    __device__ __forceinline__ float set_scaled(const Act<NBK>& x)
+    {
+        float m = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x.b[nb][r]));
+        m = xquarters_max(m);
+        const unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;            // biased exponent of the row maximum
+        // rows below 2^-63 (incl. all-zero rows) are left unscaled -- their products vanish beside any bias -- and 2^k stops at
+        // 2^63, so that scale, 1 / scale and (accumulator init) / scale stay far inside the fp32 range
+        const unsigned ec = e < 64u ? 127u : e > 190u ? 190u : e;
+        const float inv = __builtin_bit_cast(float, (254u - ec) << 23), scale = __builtin_bit_cast(float, ec << 23);
+#pragma unroll
+        for (int m2 = 0; m2 < NBK / 2; ++m2)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = (i < 4 ? x.b[2 * m2][i] : x.b[2 * m2 + 1][i - 4]) * inv;
+                const _Float16 h = (_Float16)v;
+                hi[m2][i] = h;
+                lo[m2][i] = (_Float16)((v - (float)h) * 2048.0f);
+            }
+        return scale;
     }
 };
 

@@ -129,13 +129,15 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? TI_EDGE_OCC * 4 / WAVES : 1
             A16 t1;
             if (FIRST) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
             else       r16::load_set(t1, p.e + (erow0 + j) * F, q);
-            ein.set(t1);
+            const float e_scale = ein.set_scaled(t1), e_inv = r16::pow2_inverse(e_scale);      // e is an un-normalised stream: per-row 2^k
             const float* prow = p.P + (size_t)nsrc * F;
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.acquire();
-                f32x4 a0 = r16::load_block(prow, 2 * c, q), a1 = r16::load_block(prow, 2 * c + 1, q);
+                // P[src] (the s[src] half of the Linear) / 2^k + W e' of the scaled rows, then * 2^k: all exact scalings
+                f32x4 a0 = r16::load_block(prow, 2 * c, q) * e_inv, a1 = r16::load_block(prow, 2 * c + 1, q) * e_inv;
                 r16::gemm_bt(a0, a1, ein, wl, lane);
+                a0 *= e_scale; a1 *= e_scale;
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }

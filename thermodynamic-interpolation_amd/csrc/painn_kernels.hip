@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
     A16 n2;
     {
         OP ve[3];
+        float vsc[3];                               // v is an un-normalised stream: per-row scales of the split operands
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
                 t.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);              // torch.cross(edge_dir, v[dst]) summed over edges
                 if (ok) r16::store_block(db + c * F, nb, q, t.b[nb]);
             }
-            ve[c].set(t);
+            vsc[c] = ve[c].set_scaled(t);
         }
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) n2.b[nb] = f32x4{0, 0, 0, 0};
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-                r16::gemm_bt(a0, a1, ve[c], wl, lane);                   // vv = V v
+                r16::gemm_bt(a0, a1, ve[c], wl, lane);                   // vv = V v  (of the scaled rows)
+                a0 *= vsc[c]; a1 *= vsc[c];
                 n2.b[2 * ch] += a0 * a0; n2.b[2 * ch + 1] += a1 * a1;
             }
             pipe.release();
@@ -173,33 +175,39 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
         for (int nb = 0; nb < NBK; ++nb) t.b[nb] = r16::load_block(vec + UV::B0 * F, nb, q);
         {
             OP nn;
+            float nsc;
             {
                 A16 u;
 #pragma unroll
                 for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) u.b[nb][r] = sqrtf(n2.b[nb][r]);
-                nn.set(u);
+                nsc = nn.set_scaled(u);
             }
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
-                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], nn, wl, lane);
+                f32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+                r16::gemm_bt(g0, g1, nn, wl, lane);
+                t.b[2 * ch] += g0 * nsc; t.b[2 * ch + 1] += g1 * nsc;
                 pipe.release();
             }
         }
         {
             OP ss;
+            float ssc;
             {
                 A16 u;
 #pragma unroll
                 for (int nb = 0; nb < NBK; ++nb) u.b[nb] = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);      // s += ds
-                ss.set(u);
+                ssc = ss.set_scaled(u);
             }
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
-                r16::gemm_bt(t.b[2 * ch], t.b[2 * ch + 1], ss, wl, lane);
+                f32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+                r16::gemm_bt(g0, g1, ss, wl, lane);
+                t.b[2 * ch] += g0 * ssc; t.b[2 * ch + 1] += g1 * ssc;
                 pipe.release();
             }
         }
@@ -256,11 +264,12 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
     // ---- phase C: v = v_eff + (U v_eff) * gates ; reset the accumulators for the next layer
     {
         OP ve[3];
+        float usc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             A16 t;
             r16::load_set(t, db + c * F, q);
-            ve[c].set(t);
+            usc[c] = ve[c].set_scaled(t);
         }
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
@@ -269,6 +278,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             for (int c = 0; c < 3; ++c) {
                 f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
                 r16::gemm_bt(a0, a1, ve[c], wl, lane);
+                a0 *= usc[c]; a1 *= usc[c];
                 const f32x4 e0 = r16::load_block(db + c * F, 2 * ch, q), e1 = r16::load_block(db + c * F, 2 * ch + 1, q);
                 if (ok) {
                     r16::store_block(vb + c * F, 2 * ch, q, e0 + a0 * gg.b[2 * ch]);
@@ -285,16 +295,18 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
     // ---- phase D: P for the next message block
     if (HAS_NEXT) {
         OP sn;
+        float psc;
         {
             A16 t;
             r16::load_set(t, sb, q);
-            sn.set(t);
+            psc = sn.set_scaled(t);
         }
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();
-            f32x4 a0 = r16::load_block(vec + UV::PB0 * F, 2 * ch, q), a1 = r16::load_block(vec + UV::PB0 * F, 2 * ch + 1, q);
+            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
             r16::gemm_bt(a0, a1, sn, wl, lane);
+            a0 = r16::load_block(vec + UV::PB0 * F, 2 * ch, q) + a0 * psc; a1 = r16::load_block(vec + UV::PB0 * F, 2 * ch + 1, q) + a1 * psc;
             pipe.release();
             if (ok) { r16::store_block(p.P + nd * F, 2 * ch, q, a0); r16::store_block(p.P + nd * F, 2 * ch + 1, q, a1); }
         }

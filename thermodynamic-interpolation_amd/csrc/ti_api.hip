@@ -1017,6 +1017,10 @@ ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t 
         // natural-order copy; Vr follows the 2-float readout bias in the canonical layout, so a 16-byte aligned copy of it
         // is appended for the kernels' float4 loads
         std::vector<float> flat(weights, weights + n_weights);
+        if (d->precision == TI_PREC_F16X2)          // the weights' hi halves are plain fp16: refuse what would round to inf
+            for (size_t i = 0; i < n_weights; ++i)
+                if (!(std::fabs(weights[i]) < 65504.0f))
+                    return fail(TI_E_UNSUPPORTED, "precision f16x2 needs every weight to be finite and below 65504 in magnitude (weight " + std::to_string(i) + ")");
         while (flat.size() % 4) flat.push_back(0.f);
         const size_t vr_aligned = flat.size();
         flat.insert(flat.end(), weights + h->Vr, weights + h->Vr + F);

@@ -42,6 +42,21 @@ def painn_state_dict(variant: int, F: int, L: int, n_types: int = 25, seed: int 
     return make_state_dict(W.painn_param_spec(variant, F, L, n_types), seed)
 
 
+def scale_state_dict(sd: dict, recipe) -> dict:
+    """Multiply every tensor whose key ends with one of the recipe's suffixes by that factor: recipe = [(suffix, factor), ...].
+    Used by the range fixtures (tests/golden/range_*.npz store the recipe, not the weights): e.g. scaling the edge embedding, the
+    last Linear of the embed MLP and the message output layers drives the un-normalised streams s, e, |Vv| to 1e3..1e4 or down
+    to 1e-6..1e-9, the magnitudes that matter for the split-fp16 operand path."""
+    out = {}
+    for k, v in sd.items():
+        f = 1.0
+        for suffix, factor in recipe:
+            if k.endswith(suffix):
+                f *= float(factor)
+        out[k] = (v * np.asarray(f, v.dtype)).astype(v.dtype) if f != 1.0 else v
+    return out
+
+
 def adw_state_dict(hidden: int = 256, num_layers: int = 5, seed: int = 0, dtype=np.float64) -> dict:
     return make_state_dict(W.adw_param_spec(hidden, num_layers), seed, dtype)
 
