@@ -86,11 +86,7 @@ struct Pipe {
     // start of a superchunk: kick off the global load of the following one, return the LDS image of the current one
     __device__ __forceinline__ const f32x4* begin()
     {
-#ifdef TI_ABL_NOSTREAM          // ablation build (timing only): always re-read superchunk 0, no weight streaming cost
-        const int next = 0;
-#else
         const int next = (idx + 1 == nsup) ? 0 : idx + 1;
-#endif
         const f32x4* src = g + (size_t)next * SUP4;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -159,19 +155,13 @@ struct PipeDMA {
     // LDS-DMA still in flight when the workgroup retires lands in LDS that may already belong to the next workgroup.
     __device__ __forceinline__ void drain() const
     {
-#ifndef TI_NO_DRAIN
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     }
     __device__ __forceinline__ const f32x4* acquire() const { return base + par * SUP4 + sub * CH4; }
     __device__ __forceinline__ void release()
     {
         if (sub == 0) {
-#ifdef TI_ABL_NOSTREAM
-            const int next = 0;
-#else
             const int next = (idx + 1 == nsup) ? 0 : idx + 1;
-#endif
             dma(g + (size_t)next * SUP4, base + (par ^ 1) * SUP4);
         }
         if (++sub == SC) {
@@ -417,10 +407,6 @@ __device__ __forceinline__ void load_set(Act<NBK>& a, const float* p, int q)
 template <int NBK>
 __device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const float* beta, int q)
 {
-#ifdef TI_ABL_NOLN             // ablation build (timing only, wrong results): no LayerNorm / SiLU arithmetic
-    (void)gamma; (void)beta; (void)q;
-    return;
-#endif
     constexpr float invF = 1.0f / (16.0f * NBK);
     float sum = 0.f;
 #pragma unroll
@@ -447,11 +433,6 @@ template <int NBK>
 __device__ __forceinline__ void posenc_set(Act<NBK>& a, float x_over_len, int q)
 {
     constexpr float PI_F = 3.14159265358979323846f;
-#ifdef TI_ABL_NOSINCOS         // ablation build (timing only, wrong results): no sin / cos
-#pragma unroll
-    for (int nb = 0; nb < NBK; ++nb) a.b[nb] = f32x4{x_over_len, (float)q, x_over_len, 1.0f};
-    return;
-#endif
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
         const int m = 4 * nb + q;
@@ -617,11 +598,6 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
     h8 hi[NBK / 2], lo[NBK / 2];
     __device__ __forceinline__ void set(const Act<NBK>& x)
     {
-#ifdef TI_ABL_NOCVT            // ablation build (timing only, wrong results): no hi / lo conversion arithmetic
-#pragma unroll
-        for (int m = 0; m < NBK / 2; ++m) { hi[m] = __builtin_bit_cast(h8, x.b[2 * m]); lo[m] = __builtin_bit_cast(h8, x.b[2 * m + 1]); }
-        return;
-#endif
 #pragma unroll
         for (int m = 0; m < NBK / 2; ++m)
 #pragma unroll

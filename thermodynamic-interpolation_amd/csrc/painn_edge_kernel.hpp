@@ -26,19 +26,12 @@ struct EV {
 // Fire-and-forget fp32 add (global_atomic_add_f32, no return): nothing waits for the memory round trip.  Every
 // accumulator element starts at zero and is only ever added to by the one wave that owns the molecule, in program
 // order (an atom's <= 31 incoming edges span at most three 16-row blocks of that wave).
-#ifdef TI_ABL_NOATOMIC          // ablation build (timing only, wrong results): keep the value alive, drop the memory op
-__device__ __forceinline__ void add_noret(float* p, float v) { asm volatile("" ::"v"(v), "v"(p)); }
-#else
 __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
-#endif
 
 // One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
 // The waves of a workgroup share the weight-chunk stream (4 or 8 of them, see below); two waves per SIMD (F <= 128) hide each other's
 // LayerNorm / reduction / wait phases behind matrix work.
 // SPLIT selects the split-fp16 matrix path (mfma_chain.hpp: Opnd<NBK, true>) instead of the f32 MFMA.
-#ifndef TI_EDGE_OCC
-#define TI_EDGE_OCC 2
-#endif
 // Workgroup width.  4 waves (two workgroups per CU) is the default; for large split-fp16 launches (>= 2048 groups, F <= 128)
 // the launcher picks the 8-wave build: one 512-thread workgroup per CU shares one weight stream (half the LDS-DMA writes) and, at F = 128,
 // the freed LDS holds 4-chunk superchunks (half the barriers; needs chunk counts % 4 == 0: 56/48/40/32) -- 1.8 % on the edge
@@ -46,7 +39,7 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 // 512-register budget of one wave per SIMD and is always 4 waves.
 __host__ __device__ constexpr int edge_superchunk(int NB, int WAVES) { return (WAVES == 8 && NB == 4) ? 4 : 2; }
 template <int NBK, bool FIRST, bool LAST, bool SPLIT, int WAVES, int NS>
-__global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? TI_EDGE_OCC * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
+__global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -232,11 +225,7 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? TI_EDGE_OCC * 4 / WAVES : 1
                         m2 = m2 < p.B ? m2 : p.B - 1;
                         const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
 #pragma unroll
-#ifdef TI_ABL_NOGATHER          // ablation build (timing only, wrong results): no v[src] gather
-                        for (int c = 0; c < 3; ++c) { vs[c][0][r] = 0.5f; vs[c][1][r] = 0.25f; (void)vp; }
-#else
                         for (int c = 0; c < 3; ++c) { vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16]; }
-#endif
                     }
                     out_pair(0, nbo, gt0, gt1);
                 }

@@ -31,12 +31,6 @@
 #include "mfma_chain.hpp"
 #include "ti_internal.hpp"
 
-#ifndef TI_JVP_EDGE_OCC
-#define TI_JVP_EDGE_OCC 2
-#endif
-#ifndef TI_JVP_UPD_OCC
-#define TI_JVP_UPD_OCC 2
-#endif
 
 namespace ti {
 
@@ -217,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_filter_kernel(const JvpFilte
 // One wave per virtual group.  Per (edge, direction) row only TANGENT products remain: the phi branch's hidden layers and
 // output chunks applied to the tangent of [s[src] | e]; every primal quantity comes from the primal pass above.
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, (NBK <= 8 ? TI_JVP_EDGE_OCC : 1)) void painn_jvp_edge_kernel(const JvpEdgeParams p)
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel(const JvpEdgeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;
@@ -628,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void painn_jvp_node_kernel(const JvpNodePar
 // Runs BEFORE the primal update kernel of the same layer: reads the primal v and cacc as the edge kernel left them and the
 // primal node pass output, advances ts, tv, tP; the tangent accumulators are consumed and zeroed.  Tangent products only.
 template <int NBK, bool SPLIT>
-__global__ __launch_bounds__(256, (NBK <= 8 ? TI_JVP_UPD_OCC : 1)) void painn_jvp_update_kernel(const JvpUpdateParams p)
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kernel(const JvpUpdateParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
     using A16 = r16::Act<NBK>;

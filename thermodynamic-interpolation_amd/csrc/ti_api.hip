@@ -241,7 +241,6 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
             if (waste < bestW - 1e-12) { bestW = waste; bestG = G; }
             if (waste <= 0.02) { bestG = G; break; }
         }
-        if (const char* fg = std::getenv("TI_FORCE_G")) bestG = std::max(1, std::min(8, std::atoi(fg)));      // experiments only
         ti_handle::Tpl& T = h->tpl[0];
         T.G = bestG; T.P = 1;
         T.nblk = E > 0 ? pack_part(h, dst, bestG, 0, E, T.pos) : 0;
@@ -747,7 +746,6 @@ int rollout_common(ti_handle* h, const ti_rollout_desc* rd, float* x, float* b1,
     HIP_CHECK(hipMemcpyAsync(&flag, h->nanflag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (n_fevals) *n_fevals = fe;
-    if (flag && std::getenv("TI_IGNORE_NAN")) flag = 0;          // timing-only ablation builds produce garbage on purpose
     return flag ? fail(TI_E_NAN, "non-finite value in the final state") : TI_OK;
 }
 
