@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="adw,latent,a9,a25,f256,div,dopri5")
+    ap.add_argument("--which", default="adw,latent,a9,a25,f256,div,dopri5,cfg5")
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
     import torch
@@ -66,6 +66,44 @@ def main():
         print(json.dumps({"workload": tag, "precision": precision, "trajectory_steps_per_s": B / dt, "ms_per_step": dt * 1e3,
                           "algorithmic_tflops": flop * B / dt / 1e12}))
         eng.close()
+
+    if "cfg5" in which:
+        # BASELINE.json configs[4]: ambient sampler, 1 048 576 molecules over 8 GPUs = 131 072 per GPU, "fp16 node features with MFMA
+        # linears, roofline report": precision="f16" (state tensors fp16 in HBM, one fp16 product per k-step, fp32 accumulation;
+        # DESIGN.md 3.4).  A separately labelled precision: its drift error against the reference is reported in the same line.
+        F, L, A, B = 128, 5, 18, int(os.environ.get("TI_BENCH_CFG5_B", "131072"))
+        tpl = syn.fully_connected_template(A)
+        flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, 0), W.painn_param_spec(0, F, L, 25))
+        x0 = torch.from_numpy(syn.molecule_coords(B, A, 0)).to(dev)
+        cond = torch.from_numpy(syn.ambient_cond(B, A)).to(dev)
+        grid = ti.engine.time_grid(0.0, 1.0, 2001)
+        out = torch.empty((1, B, A, 3), device=dev)
+        rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+        for prec in ("f16", "f16x2"):
+            eng = ti.engine.PainnEngine(0, F, L, A, *tpl, np.arange(A), flat, temp_length=100.0, precision=prec)
+            eng.reserve(B)
+            dt = timed(lambda k: eng.rollout(x0, cond, grid[: k + 1], scheme="em", eps=0.01, seed=1, save_every=0, out=out))
+            eng.profile(True)
+            eng.rollout(x0, cond, grid[: args.steps + 1], scheme="em", eps=0.01, seed=1, save_every=0, out=out)
+            prof = {k: eng.profile_read(k) for k in ("painn_edge", "painn_update", "painn_embed", "painn_readout")}
+            eng.profile(False)
+            edge_ms = prof["painn_edge"][1] / max(prof["painn_edge"][0], 1)
+            achieved = B * A * (A - 1) * 30 * F * F / (edge_ms * 1e-3) / 1e12
+            parity = None
+            gp = os.path.join(ROOT, "tests", "golden", "ambient_full.npz")          # the reference's own drift for exactly these weights
+            if os.path.exists(gp):
+                with np.load(gp) as g:
+                    parity = [rel(eng.drift(g["x"], float(t), g["cond"]), g[f"drift_{i}"].astype(np.float64)) for i, t in enumerate(g["ts"])]
+            flop = F * F * (L * (30 * A * (A - 1) + 24 * A) + (2 * W.N_EMBED[0] + 4) * A + 4 * A) + 10 * F * A
+            print(json.dumps({"workload": f"mdqm9 ambient (config 5 per-GPU share): {B} molecules x 18 atoms, F=128 L=5, Euler-Maruyama step",
+                              "precision": prec, "trajectory_steps_per_s": B / dt, "ms_per_step": dt * 1e3, "algorithmic_tflops": flop * B / dt / 1e12,
+                              "kernel_ms_per_launch": {k: round(v[1] / max(v[0], 1), 3) for k, v in prof.items()},
+                              "drift_rel_l2_vs_reference_pytorch_cpu": parity,
+                              "roofline": {"kernel": "painn_edge_kernel", "bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
+                                           "frac": achieved / 2500.0, "traffic": None,
+                                           "algorithmic_flop_per_launch": B * A * (A - 1) * 30 * F * F,
+                                           "products_per_algorithmic_product": 1 if prec == "f16" else 3}}))
+            eng.close()
 
     if "div" in which:
         # exact divergence: drift + trace of the Jacobian, 3A = 54 forward-mode directions per molecule.

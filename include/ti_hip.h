@@ -56,7 +56,7 @@ extern "C" {
 enum { TI_OK = 0, TI_E_ARG = -1, TI_E_HIP = -2, TI_E_NAN = -3, TI_E_ALLOC = -4, TI_E_UNSUPPORTED = -5 };
 enum { TI_MEM_HOST = 0, TI_MEM_DEVICE = 1 };
 enum { TI_VARIANT_AMBIENT = 0, TI_VARIANT_LATENT_MULTI = 1, TI_VARIANT_LATENT_SINGLE = 2 };
-enum { TI_PREC_F32 = 0, TI_PREC_F16X2 = 1 };
+enum { TI_PREC_F32 = 0, TI_PREC_F16X2 = 1, TI_PREC_F16 = 2 };
 /* Fixed-step schemes on a caller-supplied grid t[0..n_step-1] (the reference passes torch.linspace(start,end,n_step),
  * integrators.py:43; reversed grid for reverse_ode).  Build-defined (SURVEY.md F3 / §8a row I-new):
  *   EULER: x_{k+1} = x_k + dt_k b(x_k,t_k)                  (== torchdiffeq method='euler' on that grid)
@@ -89,7 +89,13 @@ typedef struct ti_painn_desc {
     float   temp_range;     /* max(temperatures) - min(...)  (embedding.py:210) */
     int32_t precision;      /* TI_PREC_F32: f32 MFMA (default); TI_PREC_F16X2: the message MLPs' matrix products on the fp16
                                matrix rate with every fp32 operand split into two fp16 halves (hi + 2^-11 lo; products
-                               hi*hi, hi*lo, lo*hi; fp32 accumulation; ~24 significand bits, operands must be < 65504) */
+                               hi*hi, hi*lo, lo*hi; fp32 accumulation; ~24 significand bits; un-normalised operand rows are
+                               scaled by a power of two first, so any fp32 magnitude works; weights must be < 65504);
+                               TI_PREC_F16: fp16 STORAGE mode (BASELINE.json configs[4]): the state tensors s, v, P, e live in HBM
+                               as fp16 and every matrix product is one fp16 MFMA with fp32 accumulation; LayerNorm, SiLU,
+                               sin/cos, per-atom sums and the integrator state x stay fp32.  A separately labelled precision:
+                               drift rel-L2 ~1e-3 against the reference (not the 1e-5 of the other two); values must stay
+                               inside the fp16 range; no divergence / dlogp / debug taps in this mode (TI_E_UNSUPPORTED) */
 } ti_painn_desc;
 
 typedef struct ti_adw_desc {

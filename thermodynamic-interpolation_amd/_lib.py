@@ -18,7 +18,7 @@ SO_PATH = os.environ.get("TI_LIB_PATH") or os.path.join(HERE, "libti_hip.so")
 TI_OK, TI_E_ARG, TI_E_HIP, TI_E_NAN, TI_E_ALLOC, TI_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 SCHEMES = {"euler": 0, "heun": 1, "em": 2, "dopri5": 3, "midpoint": 4, "rk4": 5}
-PRECISIONS = {"f32": 0, "f16x2": 1}
+PRECISIONS = {"f32": 0, "f16x2": 1, "f16": 2}
 KERNELS = {"painn_edge": 0, "painn_update": 1, "painn_embed": 2, "painn_readout": 3, "adw": 4, "integrate": 5,
            "painn_jvp_edge": 6, "painn_jvp_update": 7, "painn_jvp_readout": 8, "painn_jvp_filter": 9}
 

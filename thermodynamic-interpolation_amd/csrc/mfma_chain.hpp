@@ -233,6 +233,30 @@ __device__ __forceinline__ void store_block(float* __restrict__ p, int nb, int h
         *reinterpret_cast<f32x4*>(p + 32 * nb + 8 * g + 4 * h) = t;
     }
 }
+// the same for state tensors that may be fp16 in HBM (H16: the fp16 storage mode); elem0 = element offset of feature 0 of the row
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+template <bool H16>
+__device__ __forceinline__ f32x16 load_block_t(const float* base, size_t elem0, int nb, int h)
+{
+    if constexpr (!H16) return load_block(base + elem0, nb, h);
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const half4 t = *reinterpret_cast<const half4*>(reinterpret_cast<const _Float16*>(base) + elem0 + 32 * nb + 8 * g + 4 * h);
+        r[4 * g + 0] = (float)t[0]; r[4 * g + 1] = (float)t[1]; r[4 * g + 2] = (float)t[2]; r[4 * g + 3] = (float)t[3];
+    }
+    return r;
+}
+template <bool H16>
+__device__ __forceinline__ void store_block_t(float* base, size_t elem0, int nb, int h, const f32x16& r)
+{
+    if constexpr (!H16) { store_block(base + elem0, nb, h, r); return; }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(base) + elem0 + 32 * nb + 8 * g + 4 * h) =
+            half4{(_Float16)r[4 * g + 0], (_Float16)r[4 * g + 1], (_Float16)r[4 * g + 2], (_Float16)r[4 * g + 3]};
+}
+
 template <int NB>
 __device__ __forceinline__ void load_set(Act<NB>& a, const float* __restrict__ p, int h)
 {
@@ -684,6 +708,82 @@ __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK
 {
     gemm_split_chunk<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane);
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16-storage mode (include/ti_hip.h TI_PREC_F16; BASELINE.json configs[4] "fp16 node features with MFMA linears"): the state
+// tensors s, v, P, e live in HBM as fp16, every matrix product is ONE v_mfma_f32_16x16x32_f16 per 32-wide k-step on the fp16
+// rounding of its operands (weights: the hi halves of the split image, the lo halves are simply not read), accumulation,
+// LayerNorm, SiLU, sin / cos and the per-atom sums stay fp32.  A separately labelled precision: its drift error against the
+// reference is ~1e-3, not the 1e-5 of the other two paths (tests/test_gpu_parity.py reports it).
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+template <int NBK>
+struct OpndH {                                  // fp16 operand: NBK/2 k-steps of 8 halves, same k-slot order as Opnd<NBK, true>
+    h8 hi[NBK / 2];
+    __device__ __forceinline__ void set(const Act<NBK>& x)
+    {
+#pragma unroll
+        for (int m = 0; m < NBK / 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hi[m][i] = (_Float16)(i < 4 ? x.b[2 * m][i] : x.b[2 * m + 1][i - 4]);
+    }
+    __device__ __forceinline__ float set_scaled(const Act<NBK>& x) { set(x); return 1.0f; }
+    // a row of a fp16 [row][F] tensor IS the operand: lane (j, q) owns features 16 nb + 4 q .. + 3 of its row
+    __device__ __forceinline__ void load_row(const _Float16* row, int q)
+    {
+#pragma unroll
+        for (int m = 0; m < NBK / 2; ++m) {
+            const h4 a = *reinterpret_cast<const h4*>(row + 16 * (2 * m) + 4 * q), b = *reinterpret_cast<const h4*>(row + 16 * (2 * m + 1) + 4 * q);
+            hi[m] = h8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        }
+    }
+};
+
+template <int NBK, bool FLIP>
+__device__ __forceinline__ void gemm_half_chunk(f32x4& acc0, f32x4& acc1, const OpndH<NBK>& in, const h8* wl, int lane)
+{
+    constexpr int KS = NBK / 2, STEPS = 2 * KS;
+    h8 f[2];
+    f[0] = wl[lane];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + 1 < STEPS) f[(s + 1) & 1] = wl[(2 * (s + 1)) * 64 + lane];          // hi fragment of the next step (the lo ones are skipped)
+        __builtin_amdgcn_sched_barrier(0x16);
+        const int m = s % KS;
+        f32x4& acc = s < KS ? acc0 : acc1;
+        if (FLIP) acc = mfma16h(in.hi[m], f[s & 1], acc); else acc = mfma16h(f[s & 1], in.hi[m], acc);
+        __builtin_amdgcn_sched_barrier(0x16);
+    }
+}
+template <int NBK>
+__device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const OpndH<NBK>& in, const f32x4* wl4, int lane) { gemm_half_chunk<NBK, false>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
+template <int NBK>
+__device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const OpndH<NBK>& in, const f32x4* wl4, int lane) { gemm_half_chunk<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
+
+// operand type of a matrix path: PREC 0 = f32 MFMA, 1 = split fp16 (hi + 2^-11 lo, 3 products), 2 = fp16 storage mode (1 product)
+template <int NBK, int PREC> struct OpSel { using type = Opnd<NBK, PREC == 1>; };
+template <int NBK> struct OpSel<NBK, 2> { using type = OpndH<NBK>; };
+
+// state tensors: fp32, or fp16 in the storage mode.  One 16-feature block of a row: features 16 nb + 4 q .. + 3
+template <bool H16>
+__device__ __forceinline__ f32x4 load_state(const float* base, size_t row_elem0, int nb, int q)
+{
+    if constexpr (H16) {
+        const h4 v = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + row_elem0 + 16 * nb + 4 * q);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        return *reinterpret_cast<const f32x4*>(base + row_elem0 + 16 * nb + 4 * q);
+    }
+}
+template <bool H16>
+__device__ __forceinline__ void store_state(float* base, size_t row_elem0, int nb, int q, const f32x4& v)
+{
+    if constexpr (H16) {
+        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(base) + row_elem0 + 16 * nb + 4 * q) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    } else {
+        *reinterpret_cast<f32x4*>(base + row_elem0 + 16 * nb + 4 * q) = v;
+    }
+}
+
 // fp32 operands through the same interface
 template <int NBK>
 __device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd<NBK, false>& in, const f32x4* wl, int lane) { gemm_bt(acc0, acc1, in.a, wl, lane); }
@@ -696,7 +796,6 @@ __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK
 // f32: four 16x16x4 products (32 matrix cycles each).  Split mode: the values go through the fp16 pipe as hi + 2^-11 lo, the
 // 0/1 selector is exact in fp16: two 16x16x16 products instead -- the selection sums were a quarter of the split kernel's
 // matrix cycles.
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 template <bool SPLIT>
 __device__ __forceinline__ f32x4 select_sum(const f32x4& sel, const f32x4& v)
 {

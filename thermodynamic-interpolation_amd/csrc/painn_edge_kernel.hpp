@@ -31,19 +31,21 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 // One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
 // The waves of a workgroup share the weight-chunk stream (4 or 8 of them, see below); two waves per SIMD (F <= 128) hide each other's
 // LayerNorm / reduction / wait phases behind matrix work.
-// SPLIT selects the split-fp16 matrix path (mfma_chain.hpp: Opnd<NBK, true>) instead of the f32 MFMA.
+// PREC selects the matrix path (mfma_chain.hpp: OpSel): 0 f32 MFMA, 1 split fp16 (Opnd<NBK, true>), 2 fp16 storage mode (OpndH; the
+// state tensors P, v, e are then fp16 in HBM).
 // Workgroup width.  4 waves (two workgroups per CU) is the default; for large split-fp16 launches (>= 2048 groups, F <= 128)
 // the launcher picks the 8-wave build: one 512-thread workgroup per CU shares one weight stream (half the LDS-DMA writes) and, at F = 128,
 // the freed LDS holds 4-chunk superchunks (half the barriers; needs chunk counts % 4 == 0: 56/48/40/32) -- 1.8 % on the edge
 // kernel at B >= 32k.  Small launches keep 4 waves: fatter workgroups cost the latency regime 20-60 %.  F = 256 needs the
 // 512-register budget of one wave per SIMD and is always 4 waves.
 __host__ __device__ constexpr int edge_superchunk(int NB, int WAVES) { return (WAVES == 8 && NB == 4) ? 4 : 2; }
-template <int NBK, bool FIRST, bool LAST, bool SPLIT, int WAVES, int NS>
+template <int NBK, bool FIRST, bool LAST, int PREC, int WAVES, int NS>
 __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = 256 * NB;
+    constexpr bool H16 = PREC == 2;                 // fp16 state tensors
     using A16 = r16::Act<NBK>;
-    using OP = r16::Opnd<NBK, SPLIT>;
+    using OP = typename r16::OpSel<NBK, PREC>::type;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
     constexpr int SC = edge_superchunk(NB, WAVES);                                  // weight chunks per barrier
@@ -116,19 +118,25 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
             g2.set(t1);
         }
         // ---- phi([s[src] | e]) hidden layers; the s[src] half of the first Linear is P[src] (node kernels)
-        OP h2;
+        OP h2, ein;                                   // ein stays live in the fp16 mode: e += de reuses it (below)
         {
-            OP h1, ein;
+            OP h1;
             A16 t1;
-            if (FIRST) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
-            else       r16::load_set(t1, p.e + (erow0 + j) * F, q);
-            const float e_scale = ein.set_scaled(t1), e_inv = r16::pow2_inverse(e_scale);      // e is an un-normalised stream: per-row 2^k
-            const float* prow = p.P + (size_t)nsrc * F;
+            float e_scale = 1.0f;
+            if constexpr (H16) {
+                if (FIRST) { r16::load_set(t1, p.edge_emb + row_type(meta) * F, q); ein.set(t1); }
+                else ein.load_row(reinterpret_cast<const _Float16*>(p.e) + (erow0 + j) * F, q);        // the fp16 row IS the operand
+            } else {
+                if (FIRST) r16::load_set(t1, p.edge_emb + row_type(meta) * F, q);
+                else       r16::load_set(t1, p.e + (erow0 + j) * F, q);
+                e_scale = ein.set_scaled(t1);                                  // e is an un-normalised stream: per-row 2^k
+            }
+            const float e_inv = r16::pow2_inverse(e_scale);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const f32x4* wl = pipe.acquire();
                 // P[src] (the s[src] half of the Linear) / 2^k + W e' of the scaled rows, then * 2^k: all exact scalings
-                f32x4 a0 = r16::load_block(prow, 2 * c, q) * e_inv, a1 = r16::load_block(prow, 2 * c + 1, q) * e_inv;
+                f32x4 a0 = r16::load_state<H16>(p.P, (size_t)nsrc * F, 2 * c, q) * e_inv, a1 = r16::load_state<H16>(p.P, (size_t)nsrc * F, 2 * c + 1, q) * e_inv;
                 r16::gemm_bt(a0, a1, ein, wl, lane);
                 a0 *= e_scale; a1 *= e_scale;
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
@@ -199,7 +207,31 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                 out_pair(2, nbo, v0, v1);
                 emit(v0, v1, p.dsacc + fo, F);
             }
-            if (!LAST) {   // de: edge state update  e += de
+            if constexpr (!LAST && H16) {
+                // de in the row layout (the same two chunks with the operands the other way round): no sum over rows follows, and
+                // in this layout the old row is exactly the operand `ein` loaded above (k-step nbo = feature blocks 2 nbo, 2 nbo + 1),
+                // so e += de is two 8-byte stores per lane -- no atomics, no second read of e
+                f32x4 a0 = r16::load_block(vec + (EV::P_B2 + 3) * F, 2 * nbo, q), a1 = r16::load_block(vec + (EV::P_B2 + 3) * F, 2 * nbo + 1, q);
+                f32x4 b0 = r16::load_block(vec + (EV::W_B2 + 3) * F, 2 * nbo, q), b1 = r16::load_block(vec + (EV::W_B2 + 3) * F, 2 * nbo + 1, q);
+                const f32x4* wl0 = pipe.acquire();
+                r16::gemm_bt(a0, a1, h2, wl0, lane);
+                pipe.release();
+                const f32x4* wl1 = pipe.acquire();
+                r16::gemm_bt(b0, b1, g2, wl1, lane);
+                pipe.release();
+                r16::h4 n0, n1;
+                // runtime nbo: select the k-step of ein without dynamic register indexing
+                r16::h8 eo = ein.hi[0];
+#pragma unroll
+                for (int m = 1; m < NBK / 2; ++m) eo = nbo == m ? ein.hi[m] : eo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { n0[r] = (_Float16)((float)eo[r] + a0[r] * b0[r]); n1[r] = (_Float16)((float)eo[4 + r] + a1[r] * b1[r]); }
+                if (group_ok) {
+                    _Float16* ep = reinterpret_cast<_Float16*>(p.e) + (erow0 + j) * F + 32 * nbo + 4 * q;
+                    *reinterpret_cast<r16::h4*>(ep) = n0; *reinterpret_cast<r16::h4*>(ep + 16) = n1;
+                }
+            }
+            if constexpr (!LAST && !H16) {   // de: edge state update  e += de
                 f32x4 v0, v1;
                 out_pair(3, nbo, v0, v1);
 #pragma unroll
@@ -223,9 +255,16 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                     for (int r = 0; r < 4; ++r) {
                         long long m2 = mg * p.G + row_mol(mi[r]);
                         m2 = m2 < p.B ? m2 : p.B - 1;
-                        const float* vp = p.v + (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
+                        const size_t vo = (size_t)(m2 * p.A + row_src(mi[r])) * 3 * F + fo;
+                        if constexpr (H16) {
+                            const _Float16* vp = reinterpret_cast<const _Float16*>(p.v) + vo;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) { vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16]; }
+                            for (int c = 0; c < 3; ++c) { vs[c][0][r] = (float)vp[c * F]; vs[c][1][r] = (float)vp[c * F + 16]; }
+                        } else {
+                            const float* vp = p.v + vo;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { vs[c][0][r] = vp[c * F]; vs[c][1][r] = vp[c * F + 16]; }
+                        }
                     }
                     out_pair(0, nbo, gt0, gt1);
                 }
@@ -263,38 +302,42 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
 static size_t edge_lds_bytes(int NB, int WAVES) { return 2 * edge_superchunk(NB, WAVES) * (size_t)256 * NB * 16 + WAVES * 256 + 21 * (size_t)32 * NB * 4; }
 
 
-template <int NB, int EW, int NS>
-static hipError_t configure_edge()
+template <int NB, int EW, int NS, int PREC>
+static hipError_t configure_edge_prec()
 {
     const size_t be = edge_lds_bytes(NB, EW);
     hipError_t e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, false, false, EW, NS>, be)) != hipSuccess) return e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, false, false, EW, NS>, be)) != hipSuccess) return e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, true, false, EW, NS>, be)) != hipSuccess) return e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, true, false, EW, NS>, be)) != hipSuccess) return e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, false, true, EW, NS>, be)) != hipSuccess) return e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, false, true, EW, NS>, be)) != hipSuccess) return e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, true, true, EW, NS>, be)) != hipSuccess) return e;
-    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, true, true, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, false, PREC, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, false, PREC, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, true, PREC, EW, NS>, be)) != hipSuccess) return e;
+    if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, true, PREC, EW, NS>, be)) != hipSuccess) return e;
     return hipSuccess;
 }
-
 template <int NB, int EW, int NS>
-static void launch_edge_w(bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
+static hipError_t configure_edge()
+{
+    hipError_t e;
+    if ((e = configure_edge_prec<NB, EW, NS, 0>()) != hipSuccess) return e;
+    if ((e = configure_edge_prec<NB, EW, NS, 1>()) != hipSuccess) return e;
+    return configure_edge_prec<NB, EW, NS, 2>();
+}
+
+template <int NB, int EW, int NS, int PREC>
+static void launch_edge_p(bool first, bool last, const EdgeParams& p, hipStream_t st)
 {
     const dim3 g((unsigned)((p.n_groups + EW - 1) / EW)), t(64 * EW);          // one wave (= one group or part) each
     const size_t l = edge_lds_bytes(NB, EW);
-    if (split) {
-        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, true, EW, NS>), g, t, l, st, p);
-        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, true, EW, NS>), g, t, l, st, p);
-        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, true, EW, NS>), g, t, l, st, p);
-        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, true, EW, NS>), g, t, l, st, p);
-    } else {
-        if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, false, EW, NS>), g, t, l, st, p);
-        else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, false, EW, NS>), g, t, l, st, p);
-        else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, false, EW, NS>), g, t, l, st, p);
-        else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, false, EW, NS>), g, t, l, st, p);
-    }
+    if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, PREC, EW, NS>), g, t, l, st, p);
+    else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, PREC, EW, NS>), g, t, l, st, p);
+    else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, PREC, EW, NS>), g, t, l, st, p);
+    else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, PREC, EW, NS>), g, t, l, st, p);
+}
+template <int NB, int EW, int NS>
+static void launch_edge_w(bool first, bool last, int prec, const EdgeParams& p, hipStream_t st)
+{
+    if (prec == 2) launch_edge_p<NB, EW, NS, 2>(first, last, p, st);
+    else if (prec == 1) launch_edge_p<NB, EW, NS, 1>(first, last, p, st);
+    else launch_edge_p<NB, EW, NS, 0>(first, last, p, st);
 }
 
 // one feature width: configure every instantiation / launch the one the call needs
@@ -308,15 +351,15 @@ static hipError_t configure_edge_nb()
     return hipSuccess;
 }
 template <int NB>
-static hipError_t launch_edge_nb(bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
+static hipError_t launch_edge_nb(bool first, bool last, int prec, const EdgeParams& p, hipStream_t st)
 {
     if (p.max_slots > EDGE_MAX_SLOTS) return hipErrorInvalidValue;          // build_templates never produces such a block
     // 8-wave workgroups: split-fp16 path only (the f32 path is matrix-bound and loses 4 % to the wider barriers), enough groups to
     // fill every CU, and at most two destination atoms per row block (the only form the wide build is instantiated for)
-    const bool wide = NB <= 4 && split && p.n_groups >= 2048 && p.max_slots <= 2;
-    if constexpr (NB <= 4) { if (wide) { launch_edge_w<NB, 8, 2>(first, last, split, p, st); return hipGetLastError(); } }
-    if (p.max_slots <= 2) launch_edge_w<NB, 4, 2>(first, last, split, p, st);
-    else launch_edge_w<NB, 4, 4>(first, last, split, p, st);
+    const bool wide = NB <= 4 && prec != 0 && p.n_groups >= 2048 && p.max_slots <= 2;
+    if constexpr (NB <= 4) { if (wide) { launch_edge_w<NB, 8, 2>(first, last, prec, p, st); return hipGetLastError(); } }
+    if (p.max_slots <= 2) launch_edge_w<NB, 4, 2>(first, last, prec, p, st);
+    else launch_edge_w<NB, 4, 4>(first, last, prec, p, st);
     return hipGetLastError();
 }
 

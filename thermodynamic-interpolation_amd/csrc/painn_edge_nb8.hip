@@ -3,5 +3,5 @@
 
 namespace ti {
 hipError_t configure_edge_nb8() { return configure_edge_nb<8>(); }
-hipError_t launch_edge_nb8(bool first, bool last, bool split, const EdgeParams& p, hipStream_t st) { return launch_edge_nb<8>(first, last, split, p, st); }
+hipError_t launch_edge_nb8(bool first, bool last, int prec, const EdgeParams& p, hipStream_t st) { return launch_edge_nb<8>(first, last, prec, p, st); }
 }  // namespace ti

@@ -20,8 +20,8 @@ namespace ti {
 
 // the edge kernels live in painn_edge_nb{1,2,4,8}.hip (painn_edge_kernel.hpp)
 hipError_t configure_edge_nb1(); hipError_t configure_edge_nb2(); hipError_t configure_edge_nb4(); hipError_t configure_edge_nb8();
-hipError_t launch_edge_nb1(bool, bool, bool, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb2(bool, bool, bool, const EdgeParams&, hipStream_t);
-hipError_t launch_edge_nb4(bool, bool, bool, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb8(bool, bool, bool, const EdgeParams&, hipStream_t);
+hipError_t launch_edge_nb1(bool, bool, int, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb2(bool, bool, int, const EdgeParams&, hipStream_t);
+hipError_t launch_edge_nb4(bool, bool, int, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb8(bool, bool, int, const EdgeParams&, hipStream_t);
 
 template <int NB, int WAVES>
 struct Cfg {
@@ -33,7 +33,7 @@ struct Cfg {
 
 // ================================================================================================== embed kernel
 // s = MLP([atom_emb | enc(T0) | enc(T1) | enc(t)]),  P = s @ phi0.W0[:, :F]^T + phi0.b0
-template <int NB, int WAVES, int NSEG>
+template <int NB, int WAVES, int NSEG, bool H16>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_embed_kernel(const EmbedParams p)
 {
     using C = Cfg<NB, WAVES>;
@@ -90,14 +90,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_embed_kernel(cons
         sset.b[nbo] = a;
         pipe.end();
     }
-    if (ok) store_set(p.s + (size_t)node * F, h, sset);
+    if (ok) {
+#pragma unroll
+        for (int nbo = 0; nbo < NB; ++nbo) store_block_t<H16>(p.s, (size_t)node * F, nbo, h, sset.b[nbo]);
+    }
 #pragma unroll
     for (int nbo = 0; nbo < NB; ++nbo) {
         const f32x4* wl = pipe.begin();
         f32x16 a = load_block(p.pb0, nbo, h);
         gemm_bt(a, sset, wl, lane);
         pipe.end();
-        if (ok) store_block(p.P + (size_t)node * F, nbo, h, a);
+        if (ok) store_block_t<H16>(p.P, (size_t)node * F, nbo, h, a);
     }
 }
 
@@ -110,12 +113,13 @@ struct UV {                                         // per-layer vector block in
     static constexpr int B0 = 0, G0 = 1, BE0 = 2, B1 = 3, G1 = 4, BE1 = 5, B2 = 6 /* 3F: gates | scale | add */, PB0 = 9, COUNT = 10;
 };
 
-template <int NBK, bool HAS_NEXT, bool SPLIT>
+template <int NBK, bool HAS_NEXT, int PREC>
 __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(const UpdateParams p)
 {
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
+    constexpr bool H16 = PREC == 2;                 // s, v, P are fp16 in HBM (the accumulators stay fp32)
     using A16 = r16::Act<NBK>;
-    using OP = r16::Opnd<NBK, SPLIT>;
+    using OP = typename r16::OpSel<NBK, PREC>::type;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
     float* vec = reinterpret_cast<float*>(lds + 4 * CH4);                          // [UV::COUNT][F]
@@ -127,10 +131,9 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
     const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
     const bool ok = node < p.N;
     const size_t nd = (size_t)(ok ? node : p.N - 1);
-    float* vb = p.v + nd * 3 * F;
+    const size_t vo = nd * 3 * F, so_ = nd * F;   // element offsets of this node's v / s rows (fp32 or fp16 storage)
     float* db = p.dvacc + nd * 3 * F;
     float* cb = p.cacc + nd * 3 * F;
-    float* sb = p.s + nd * F;
     float* ab = p.dsacc + nd * F;                 // sum of the invariant messages of this layer (edge kernel)
 
     // ---- phase A: v_eff = v + dvacc + cacc x v (parked in dvacc), n2 = |V v_eff|^2 over the 3 components
@@ -144,8 +147,8 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             A16 t;
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) {
-                const f32x4 vc = r16::load_block(vb + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
-                const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
+                const f32x4 vc = r16::load_state<H16>(p.v, vo + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
+                const f32x4 v1 = r16::load_state<H16>(p.v, vo + c1 * F, nb, q), v2 = r16::load_state<H16>(p.v, vo + c2 * F, nb, q);
                 const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
                 t.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);              // torch.cross(edge_dir, v[dst]) summed over edges
                 if (ok) r16::store_block(db + c * F, nb, q, t.b[nb]);
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             {
                 A16 u;
 #pragma unroll
-                for (int nb = 0; nb < NBK; ++nb) u.b[nb] = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);      // s += ds
+                for (int nb = 0; nb < NBK; ++nb) u.b[nb] = r16::load_state<H16>(p.s, so_, nb, q) + r16::load_block(ab, nb, q);      // s += ds
                 ssc = ss.set_scaled(u);
             }
 #pragma unroll
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int nb = 2 * ch + k;
-            f32x4 so = r16::load_block(sb, nb, q) + r16::load_block(ab, nb, q);
+            f32x4 so = r16::load_state<H16>(p.s, so_, nb, q) + r16::load_block(ab, nb, q);
             const f32x4 qq = k ? q1 : q0, aa = k ? a1 : a0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
                 so[r] = so[r] + ((n * n) * qq[r] + aa[r]);              // s += vv_norm**2 * scale + add
             }
             if (ok) {
-                r16::store_block(sb, nb, q, so);
+                r16::store_state<H16>(p.s, so_, nb, q, so);
                 r16::store_block(ab, nb, q, f32x4{0, 0, 0, 0});
             }
         }
@@ -281,8 +284,8 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
                 a0 *= usc[c]; a1 *= usc[c];
                 const f32x4 e0 = r16::load_block(db + c * F, 2 * ch, q), e1 = r16::load_block(db + c * F, 2 * ch + 1, q);
                 if (ok) {
-                    r16::store_block(vb + c * F, 2 * ch, q, e0 + a0 * gg.b[2 * ch]);
-                    r16::store_block(vb + c * F, 2 * ch + 1, q, e1 + a1 * gg.b[2 * ch + 1]);
+                    r16::store_state<H16>(p.v, vo + c * F, 2 * ch, q, e0 + a0 * gg.b[2 * ch]);
+                    r16::store_state<H16>(p.v, vo + c * F, 2 * ch + 1, q, e1 + a1 * gg.b[2 * ch + 1]);
                     r16::store_block(db + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
                     r16::store_block(db + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
                     r16::store_block(cb + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
@@ -298,7 +301,8 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
         float psc;
         {
             A16 t;
-            r16::load_set(t, sb, q);
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) t.b[nb] = r16::load_state<H16>(p.s, so_, nb, q);
             psc = sn.set_scaled(t);
         }
 #pragma unroll
@@ -308,14 +312,14 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             r16::gemm_bt(a0, a1, sn, wl, lane);
             a0 = r16::load_block(vec + UV::PB0 * F, 2 * ch, q) + a0 * psc; a1 = r16::load_block(vec + UV::PB0 * F, 2 * ch + 1, q) + a1 * psc;
             pipe.release();
-            if (ok) { r16::store_block(p.P + nd * F, 2 * ch, q, a0); r16::store_block(p.P + nd * F, 2 * ch + 1, q, a1); }
+            if (ok) { r16::store_state<H16>(p.P, nd * F, 2 * ch, q, a0); r16::store_state<H16>(p.P, nd * F, 2 * ch + 1, q, a1); }
         }
     }
     pipe.drain();
 }
 
 // ================================================================================================== readout kernel
-template <int NB, int WAVES>
+template <int NB, int WAVES, bool H16>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_readout_kernel(const ReadoutParams p)
 {
     using C = Cfg<NB, WAVES>;
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_readout_kernel(co
     Act<NB> h1, h2;
     {
         Act<NB> ss;
-        load_set(ss, p.s + nd * F, h);
+#pragma unroll
+        for (int nbo = 0; nbo < NB; ++nbo) ss.b[nbo] = load_block_t<H16>(p.s, nd * F, nbo, h);
 #pragma unroll
         for (int nbo = 0; nbo < NB; ++nbo) {
             const f32x4* wl = pipe.begin();
@@ -356,7 +361,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_readout_kernel(co
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         Act<NB> vc;
-        load_set(vc, p.v + (nd * 3 + c) * F, h);
+#pragma unroll
+        for (int nbo = 0; nbo < NB; ++nbo) vc.b[nbo] = load_block_t<H16>(p.v, (nd * 3 + c) * F, nbo, h);
         const float vv = dot_set(vc, p.Vr, h);
         if (ok && h == 0) p.out[node * 3 + c] = vv * gate;
     }
@@ -377,14 +383,17 @@ static hipError_t configure_nb()
     const size_t b = Cfg<NB, WAVES>::lds_bytes;
     hipError_t e;
 #define TI_SET(k) if ((e = set_lds(k, b)) != hipSuccess) return e
-    TI_SET((painn_embed_kernel<NB, WAVES, 2>)); TI_SET((painn_embed_kernel<NB, WAVES, 3>)); TI_SET((painn_embed_kernel<NB, WAVES, 4>));
+    TI_SET((painn_embed_kernel<NB, WAVES, 2, false>)); TI_SET((painn_embed_kernel<NB, WAVES, 3, false>)); TI_SET((painn_embed_kernel<NB, WAVES, 4, false>));
+    TI_SET((painn_embed_kernel<NB, WAVES, 2, true>)); TI_SET((painn_embed_kernel<NB, WAVES, 3, true>)); TI_SET((painn_embed_kernel<NB, WAVES, 4, true>));
     if ((e = (NB == 1 ? configure_edge_nb1() : NB == 2 ? configure_edge_nb2() : NB == 4 ? configure_edge_nb4() : configure_edge_nb8())) != hipSuccess) return e;
     const size_t bu = update_lds_bytes(NB);
-    if ((e = set_lds(painn_update_kernel<2 * NB, true, false>, bu)) != hipSuccess) return e;
-    if ((e = set_lds(painn_update_kernel<2 * NB, false, false>, bu)) != hipSuccess) return e;
-    if ((e = set_lds(painn_update_kernel<2 * NB, true, true>, bu)) != hipSuccess) return e;
-    if ((e = set_lds(painn_update_kernel<2 * NB, false, true>, bu)) != hipSuccess) return e;
-    TI_SET((painn_readout_kernel<NB, WAVES>));
+    if ((e = set_lds(painn_update_kernel<2 * NB, true, 0>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, false, 0>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, true, 1>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, false, 1>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, true, 2>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, false, 2>, bu)) != hipSuccess) return e;
+    TI_SET((painn_readout_kernel<NB, WAVES, false>)); TI_SET((painn_readout_kernel<NB, WAVES, true>));
 #undef TI_SET
     return hipSuccess;
 }
@@ -414,52 +423,63 @@ hipError_t configure_painn_kernels(int NBv)
 template <int NB, int WAVES>
 static dim3 node_grid(long long N) { return dim3((unsigned)((N + 32LL * WAVES - 1) / (32LL * WAVES))); }
 
-hipError_t launch_embed(int NBv, int nseg, const EmbedParams& p, hipStream_t st)
+// prec: include/ti_hip.h TI_PREC_* (0 f32, 1 f16x2, 2 f16 storage mode: the state tensors are fp16)
+hipError_t launch_embed(int NBv, int nseg, int prec, const EmbedParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
         const dim3 g = node_grid<NB, WAVES>(p.N);
         const size_t l = Cfg<NB, WAVES>::lds_bytes;
-        if (nseg == 4) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 4>), g, dim3(64 * WAVES), l, st, p);
-        else if (nseg == 3) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 3>), g, dim3(64 * WAVES), l, st, p);
-        else hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 2>), g, dim3(64 * WAVES), l, st, p);
-    });
-    return hipGetLastError();
-}
-
-hipError_t launch_edge(int NBv, bool first, bool last, bool split, const EdgeParams& p, hipStream_t st)
-{
-    switch (NBv) {
-        case 1: return launch_edge_nb1(first, last, split, p, st);
-        case 2: return launch_edge_nb2(first, last, split, p, st);
-        case 4: return launch_edge_nb4(first, last, split, p, st);
-        case 8: return launch_edge_nb8(first, last, split, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-hipError_t launch_update(int NBv, bool has_next, bool split, const UpdateParams& p, hipStream_t st)
-{
-    TI_DISPATCH_NB(NBv, {
-        (void)WAVES;
-        const dim3 g((unsigned)((p.N + 63) / 64));                 // 4 waves x 16 atoms per workgroup
-        const size_t l = update_lds_bytes(NB);
-        if (split) {
-            if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, true>), g, dim3(256), l, st, p);
-            else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, true>), g, dim3(256), l, st, p);
+        if (prec == 2) {
+            if (nseg == 4) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 4, true>), g, dim3(64 * WAVES), l, st, p);
+            else if (nseg == 3) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 3, true>), g, dim3(64 * WAVES), l, st, p);
+            else hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 2, true>), g, dim3(64 * WAVES), l, st, p);
         } else {
-            if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, false>), g, dim3(256), l, st, p);
-            else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, false>), g, dim3(256), l, st, p);
+            if (nseg == 4) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 4, false>), g, dim3(64 * WAVES), l, st, p);
+            else if (nseg == 3) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 3, false>), g, dim3(64 * WAVES), l, st, p);
+            else hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 2, false>), g, dim3(64 * WAVES), l, st, p);
         }
     });
     return hipGetLastError();
 }
 
-hipError_t launch_readout(int NBv, const ReadoutParams& p, hipStream_t st)
+hipError_t launch_edge(int NBv, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st)
+{
+    switch (NBv) {
+        case 1: return launch_edge_nb1(first, last, prec, p, st);
+        case 2: return launch_edge_nb2(first, last, prec, p, st);
+        case 4: return launch_edge_nb4(first, last, prec, p, st);
+        case 8: return launch_edge_nb8(first, last, prec, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_update(int NBv, bool has_next, int prec, const UpdateParams& p, hipStream_t st)
+{
+    TI_DISPATCH_NB(NBv, {
+        (void)WAVES;
+        const dim3 g((unsigned)((p.N + 63) / 64));                 // 4 waves x 16 atoms per workgroup
+        const size_t l = update_lds_bytes(NB);
+        if (prec == 2) {
+            if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, 2>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, 2>), g, dim3(256), l, st, p);
+        } else if (prec == 1) {
+            if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, 1>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, 1>), g, dim3(256), l, st, p);
+        } else {
+            if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, 0>), g, dim3(256), l, st, p);
+            else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, 0>), g, dim3(256), l, st, p);
+        }
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_readout(int NBv, int prec, const ReadoutParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
         const dim3 g = node_grid<NB, WAVES>(p.N);
         const size_t l = Cfg<NB, WAVES>::lds_bytes;
-        hipLaunchKernelGGL((painn_readout_kernel<NB, WAVES>), g, dim3(64 * WAVES), l, st, p);
+        if (prec == 2) hipLaunchKernelGGL((painn_readout_kernel<NB, WAVES, true>), g, dim3(64 * WAVES), l, st, p);
+        else hipLaunchKernelGGL((painn_readout_kernel<NB, WAVES, false>), g, dim3(64 * WAVES), l, st, p);
     });
     return hipGetLastError();
 }

@@ -351,7 +351,7 @@ void pack_painn(ti_handle* h, const float* wts)
     else for (int nbo = 0; nbo < NB; ++nbo) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f);
     h->st_embed = end_stream(o);
     const int NBK = F / 16;
-    const bool split = h->d.precision == TI_PREC_F16X2;
+    const bool split = h->d.precision != TI_PREC_F32;          // f16x2 and f16 read the (hi, lo) fp16 image (f16: the hi halves only)
     auto chunk16 = [&](size_t W, int ld, int n_rows, int row0, int col0) {
         if (split) pack_chunk16_split(pk, wts + W, ld, n_rows, row0, col0, NBK); else pack_chunk16(pk, wts + W, ld, n_rows, row0, col0, NBK);
     };
@@ -460,9 +460,10 @@ void ensure_painn_ws(ti_handle* h, long long B)
     const size_t A = h->d.n_atoms, F = h->d.n_features, N = (size_t)B * A;
     h->x.alloc(N * 3); h->b1.alloc(N * 3); h->b2.alloc(N * 3); h->xt.alloc(N * 3);
     h->cond.alloc(std::max<size_t>(N * h->ncond, 1));
-    h->s.alloc(N * F); h->P.alloc(N * F);
-    h->v.alloc(N * 3 * F); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F); h->dsacc.alloc(N * F);
-    h->e.alloc(edge_rows_for(h, B) * F);
+    const size_t se = h->d.precision == TI_PREC_F16 ? 2 : 1;      // state tensors s, P, v, e: fp16 in the storage mode (2 per float slot)
+    h->s.alloc((N * F + se - 1) / se); h->P.alloc((N * F + se - 1) / se);
+    h->v.alloc((N * 3 * F + se - 1) / se); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F); h->dsacc.alloc(N * F);
+    h->e.alloc((edge_rows_for(h, B) * F + se - 1) / se);
     h->divb.alloc(B); h->div2.alloc(B); h->dl.alloc(B); h->dlscaled.alloc(B);
     h->cap = B;
 }
@@ -525,6 +526,8 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     const long long N = B * A, groups = (B + h->G - 1) / h->G * h->parts;         // edge-kernel waves: (molecule group, part)
     hipStream_t st = h->stream;
     const bool split = h->d.precision == TI_PREC_F16X2;
+    const int prec = h->d.precision;
+    if (jr && prec == TI_PREC_F16) throw std::invalid_argument("the fp16 storage mode has no divergence / tangent path (use f32 or f16x2)");
     const long long VB = jr ? jvp_virtual_molecules(h, B, jr->D) : 0, VN = VB * A, vgroups = VB / h->G * h->parts;
     if (jr) {
         ensure_jvp_ws(h, B, jr->D);
@@ -536,7 +539,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         HIP_CHECK(hipMemsetAsync(h->tcacc.p, 0, 3 * nb, st));
     }
     const size_t vbytes = (size_t)N * 3 * F * sizeof(float);
-    HIP_CHECK(hipMemsetAsync(h->v.p, 0, vbytes, st));
+    HIP_CHECK(hipMemsetAsync(h->v.p, 0, prec == TI_PREC_F16 ? vbytes / 2 : vbytes, st));
     HIP_CHECK(hipMemsetAsync(h->dvacc.p, 0, vbytes, st));
     HIP_CHECK(hipMemsetAsync(h->cacc.p, 0, vbytes, st));
     HIP_CHECK(hipMemsetAsync(h->dsacc.p, 0, (size_t)N * F * sizeof(float), st));
@@ -548,7 +551,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         p.t = t; p.temp_length = h->d.temp_length; p.time_length = h->d.time_length; p.temp_mean = h->d.temp_mean; p.temp_range = h->d.temp_range;
         p.s = h->s.p; p.P = h->P.p;
         Timed tm(h, TI_KERNEL_PAINN_EMBED);
-        HIP_CHECK(launch_embed(NB, h->nE, p, st));
+        HIP_CHECK(launch_embed(NB, h->nE, prec, p, st));
     }
     h->last_B = B;
     if (h->tap == 0) return;
@@ -581,7 +584,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.max_slots = h->max_slots; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
             p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
-            HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, h->d.precision == TI_PREC_F16X2, p, st));
+            HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
         }
         if (h->tap == 1 + 2 * l) return;
         if (jr) {
@@ -606,7 +609,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             p.stream = h->S(h->st_update[l]); p.nch = h->st_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
             p.N = N; p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.P = h->P.p;
             Timed tm(h, TI_KERNEL_PAINN_UPDATE);
-            HIP_CHECK(launch_update(NB, l + 1 < L, h->d.precision == TI_PREC_F16X2, p, st));
+            HIP_CHECK(launch_update(NB, l + 1 < L, prec, p, st));
         }
         if (h->tap == 2 + 2 * l) return;
     }
@@ -623,7 +626,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         p.w2_gate = h->F(h->readout.W2 + F); p.b2_gate = h->b2_gate; p.Vr = h->F(h->Vr);
         p.N = N; p.s = h->s.p; p.v = h->v.p; p.out = out_dev;
         Timed tm(h, TI_KERNEL_PAINN_READOUT);
-        HIP_CHECK(launch_readout(NB, p, st));
+        HIP_CHECK(launch_readout(NB, prec, p, st));
     }
 }
 
@@ -989,7 +992,7 @@ ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t 
         if (E < 0 || (E > 0 && (!edge_src || !edge_dst || !edge_type))) return fail(TI_E_ARG, "edge arrays missing");
         if (d->variant < 0 || d->variant > 2) return fail(TI_E_ARG, "unknown variant");
         if (d->n_types < 1) return fail(TI_E_ARG, "n_types must be >= 1");
-        if (d->precision != TI_PREC_F32 && d->precision != TI_PREC_F16X2) return fail(TI_E_ARG, "unknown precision");
+        if (d->precision != TI_PREC_F32 && d->precision != TI_PREC_F16X2 && d->precision != TI_PREC_F16) return fail(TI_E_ARG, "unknown precision");
         for (int k = 0; k < E; ++k)
             if (edge_src[k] < 0 || edge_src[k] >= A || edge_dst[k] < 0 || edge_dst[k] >= A || edge_type[k] < 0 || edge_type[k] > 3)
                 return fail(TI_E_ARG, "edge index / type out of range");
@@ -1015,10 +1018,10 @@ ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t 
         // natural-order copy; Vr follows the 2-float readout bias in the canonical layout, so a 16-byte aligned copy of it
         // is appended for the kernels' float4 loads
         std::vector<float> flat(weights, weights + n_weights);
-        if (d->precision == TI_PREC_F16X2)          // the weights' hi halves are plain fp16: refuse what would round to inf
+        if (d->precision != TI_PREC_F32)            // the weights' hi halves are plain fp16: refuse what would round to inf
             for (size_t i = 0; i < n_weights; ++i)
                 if (!(std::fabs(weights[i]) < 65504.0f))
-                    return fail(TI_E_UNSUPPORTED, "precision f16x2 needs every weight to be finite and below 65504 in magnitude (weight " + std::to_string(i) + ")");
+                    return fail(TI_E_UNSUPPORTED, "precisions f16x2 / f16 need every weight to be finite and below 65504 in magnitude (weight " + std::to_string(i) + ")");
         while (flat.size() % 4) flat.push_back(0.f);
         const size_t vr_aligned = flat.size();
         flat.insert(flat.end(), weights + h->Vr, weights + h->Vr + F);
@@ -1095,6 +1098,7 @@ int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t,
                        float* out_tan, int mem)
 {
     if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (h->d.precision == TI_PREC_F16) return fail(TI_E_UNSUPPORTED, "the fp16 storage mode has no divergence / tangent path (use f32 or f16x2)");
     if (B < 0 || (B > 0 && (!x || !xdot || !out || !out_tan || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
     if (B == 0) return TI_OK;
     return guarded([&]() -> int {
@@ -1124,6 +1128,7 @@ int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t,
 int ti_painn_drift_div(ti_handle* h, const float* x, float t, const float* cond, int64_t B, float* out, float* out_div, int mem)
 {
     if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (h->d.precision == TI_PREC_F16) return fail(TI_E_UNSUPPORTED, "the fp16 storage mode has no divergence / tangent path (use f32 or f16x2)");
     if (B < 0 || (B > 0 && (!x || !out || !out_div || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
     if (B == 0) return TI_OK;
     if (h->tap >= 0) return fail(TI_E_ARG, "debug taps apply to ti_painn_drift / ti_painn_drift_jvp only");
@@ -1152,6 +1157,7 @@ int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* rd, const float*
                            float out_scale, int reverse_ode, float* out_path, float* out_dlogp, int64_t* n_fevals)
 {
     if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (h->d.precision == TI_PREC_F16) return fail(TI_E_UNSUPPORTED, "the fp16 storage mode has no divergence / tangent path (use f32 or f16x2)");
     if (int rc = check_rollout_desc(rd)) return rc;
     if (rd->scheme == TI_SCHEME_EM) return fail(TI_E_UNSUPPORTED, "dlogp is defined for the deterministic schemes only (EULER, HEUN)");
     if (B < 0 || (B > 0 && (!x0 || !out_path || !out_dlogp || (h->ncond > 0 && !cond)))) return fail(TI_E_ARG, "NULL buffer");
@@ -1187,6 +1193,7 @@ int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* rd, const float*
 int ti_painn_debug_tap(ti_handle* h, int stage)
 {
     if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
+    if (h->d.precision == TI_PREC_F16 && stage >= 0) return fail(TI_E_UNSUPPORTED, "debug taps read fp32 state; not available in the fp16 storage mode");
     h->tap = stage;
     return TI_OK;
 }

@@ -78,10 +78,11 @@ struct ReadoutParams {
 };
 
 // launchers (painn_kernels.hip).  F = 32*NB; return hipError_t of the launch.
-hipError_t launch_embed(int NB, int nseg, const EmbedParams& p, hipStream_t st);
-hipError_t launch_edge(int NB, bool first, bool last, bool split, const EdgeParams& p, hipStream_t st);
-hipError_t launch_update(int NB, bool has_next, bool split, const UpdateParams& p, hipStream_t st);
-hipError_t launch_readout(int NB, const ReadoutParams& p, hipStream_t st);
+// prec = TI_PREC_* of include/ti_hip.h; with TI_PREC_F16 the state tensors s, P, v, e behind the float* fields are fp16
+hipError_t launch_embed(int NB, int nseg, int prec, const EmbedParams& p, hipStream_t st);
+hipError_t launch_edge(int NB, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st);
+hipError_t launch_update(int NB, bool has_next, int prec, const UpdateParams& p, hipStream_t st);
+hipError_t launch_readout(int NB, int prec, const ReadoutParams& p, hipStream_t st);
 hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
 
 // ---- forward-mode derivative of the drift (painn_jvp_kernels.hip; virtual-molecule layout described there).

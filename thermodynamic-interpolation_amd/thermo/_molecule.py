@@ -63,7 +63,7 @@ class PaiNNShell:
         self._spec = _W.painn_param_spec(self.VARIANT, self.n_features, self.score_layers, self.n_types)
         self._sd = _syn.make_state_dict(self._spec, seed=0)       # placeholder init; real weights come from load_state_dict
         self._engines, self._device = {}, 0
-        self.precision = "f32"                  # 'f16x2': split-fp16 matrix path; set before first use
+        self.precision = "f32"                  # 'f16x2': split-fp16 matrix path; 'f16': fp16 storage mode; set before first use
         self.training = False
 
     # -- torch.nn.Module surface used by the sampling drivers (sample_ambient.py:71-72,125-131)
