@@ -616,6 +616,7 @@ struct Opnd {                                   // fp32 operand: the activation 
     Act<NBK> a;
     __device__ __forceinline__ void set(const Act<NBK>& x) { a = x; }
     __device__ __forceinline__ float set_scaled(const Act<NBK>& x) { a = x; return 1.0f; }
+    __device__ __forceinline__ f32x4 value(int nb, float) const { return a.b[nb]; }          // the block the operand was set from (exact)
 };
 template <int NBK>
 struct Opnd<NBK, true> {                        // split operand: hi and scaled-lo halves, NBK/2 k-steps
@@ -661,6 +662,17 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
                 lo[m2][i] = (_Float16)((v - (float)h) * 2048.0f);
             }
         return scale;
+    }
+    // Block nb of the set the operand was made from, rebuilt from its halves: (hi + 2^-11 lo) * scale, every step exact, i.e. the
+    // original to ~23 bits (|error| <= 2^-23 |x| for values within 2^-13 of their row's maximum, <= 2^-36 of that maximum below).
+    // Lets a kernel that already holds a row as an operand use it again as a value instead of reading it from HBM a second time.
+    __device__ __forceinline__ f32x4 value(int nb, float scale) const
+    {
+        const int m = nb >> 1, o = 4 * (nb & 1);
+        f32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = ((float)hi[m][o + i] + (float)lo[m][o + i] * 4.8828125e-4f) * scale;
+        return r;
     }
 };
 

@@ -113,6 +113,9 @@ struct UV {                                         // per-layer vector block in
     static constexpr int B0 = 0, G0 = 1, BE0 = 2, B1 = 3, G1 = 4, BE1 = 5, B2 = 6 /* 3F: gates | scale | add */, PB0 = 9, COUNT = 10;
 };
 
+// weight chunks per barrier.  4 (64 KB in flight per workgroup) was tried for the latency regime: no change (A = 9, B = 12: 59 vs 60 us),
+// the stream of a lone workgroup runs at the ~12 B/clk a CU gets from beyond L2, not at the number of bytes in flight
+__host__ __device__ constexpr int update_superchunk(int) { return 2; }
 template <int NBK, bool HAS_NEXT, int PREC>
 __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(const UpdateParams p)
 {
@@ -122,10 +125,11 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
     using OP = typename r16::OpSel<NBK, PREC>::type;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    float* vec = reinterpret_cast<float*>(lds + 4 * CH4);                          // [UV::COUNT][F]
+    constexpr int SC = update_superchunk(NB);
+    float* vec = reinterpret_cast<float*>(lds + 2 * SC * CH4);                     // [UV::COUNT][F]
     for (int i = threadIdx.x; i < UV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    PipeDMA<NB, T, 2> pipe;
+    PipeDMA<NB, T, SC> pipe;
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
     const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
@@ -141,19 +145,23 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
     {
         OP ve[3];
         float vsc[3];                               // v is an un-normalised stream: per-row scales of the split operands
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-            A16 t;
-#pragma unroll
+        {
+            A16 t[3];                               // feature block outermost: v, dvacc and cacc are each read ONCE (all three components of a
+#pragma unroll                                      // block are needed for the cross product; re-reading them per component missed L2)
             for (int nb = 0; nb < NBK; ++nb) {
-                const f32x4 vc = r16::load_state<H16>(p.v, vo + c * F, nb, q), dd = r16::load_block(db + c * F, nb, q);
-                const f32x4 v1 = r16::load_state<H16>(p.v, vo + c1 * F, nb, q), v2 = r16::load_state<H16>(p.v, vo + c2 * F, nb, q);
-                const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
-                t.b[nb] = (vc + dd) + (k1 * v2 - k2 * v1);              // torch.cross(edge_dir, v[dst]) summed over edges
-                if (ok) r16::store_block(db + c * F, nb, q, t.b[nb]);
+                f32x4 vv[3], kk[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { vv[c] = r16::load_state<H16>(p.v, vo + c * F, nb, q); kk[c] = r16::load_block(cb + c * F, nb, q); }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                    const f32x4 dd = r16::load_block(db + c * F, nb, q);
+                    t[c].b[nb] = (vv[c] + dd) + (kk[c1] * vv[c2] - kk[c2] * vv[c1]);      // torch.cross(edge_dir, v[dst]) summed over edges
+                    if (ok) r16::store_block(db + c * F, nb, q, t[c].b[nb]);
+                }
             }
-            vsc[c] = ve[c].set_scaled(t);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vsc[c] = ve[c].set_scaled(t[c]);
         }
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) n2.b[nb] = f32x4{0, 0, 0, 0};
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
         }
     }
     // ---- phase B: MLP([ |vv| , s ])
+    A16 snew;                                       // s + ds, then s after the update (phase D's operand): read once, kept in registers
     OP h2;
     {
         A16 t;
@@ -199,12 +208,9 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
         {
             OP ss;
             float ssc;
-            {
-                A16 u;
 #pragma unroll
-                for (int nb = 0; nb < NBK; ++nb) u.b[nb] = r16::load_state<H16>(p.s, so_, nb, q) + r16::load_block(ab, nb, q);      // s += ds
-                ssc = ss.set_scaled(u);
-            }
+            for (int nb = 0; nb < NBK; ++nb) snew.b[nb] = r16::load_state<H16>(p.s, so_, nb, q) + r16::load_block(ab, nb, q);      // s += ds
+            ssc = ss.set_scaled(snew);
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
@@ -242,13 +248,14 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int nb = 2 * ch + k;
-            f32x4 so = r16::load_state<H16>(p.s, so_, nb, q) + r16::load_block(ab, nb, q);
+            f32x4 so = snew.b[nb];
             const f32x4 qq = k ? q1 : q0, aa = k ? a1 : a0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float n = sqrtf(n2.b[nb][r]);
                 so[r] = so[r] + ((n * n) * qq[r] + aa[r]);              // s += vv_norm**2 * scale + add
             }
+            snew.b[nb] = so;
             if (ok) {
                 r16::store_state<H16>(p.s, so_, nb, q, so);
                 r16::store_block(ab, nb, q, f32x4{0, 0, 0, 0});
@@ -264,33 +271,28 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
         gg.b[2 * ch] = a0; gg.b[2 * ch + 1] = a1;
         pipe.release();
     }
-    // ---- phase C: v = v_eff + (U v_eff) * gates ; reset the accumulators for the next layer
-    {
-        OP ve[3];
-        float usc[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            A16 t;
-            r16::load_set(t, db + c * F, q);
-            usc[c] = ve[c].set_scaled(t);
-        }
+    // ---- phase C: v = v_eff + (U v_eff) * gates ; reset the accumulators for the next layer.  One spatial component at a time (the
+    // stream holds U three times): the parked v_eff row is read once and serves as operand AND as the value the update is added to
+    // -- with the three components sharing each chunk visit it had to be read a second time, and that read missed L2.
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        A16 t;
+        r16::load_set(t, db + c * F, q);
+        OP vc;
+        const float usc = vc.set_scaled(t);
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-                r16::gemm_bt(a0, a1, ve[c], wl, lane);
-                a0 *= usc[c]; a1 *= usc[c];
-                const f32x4 e0 = r16::load_block(db + c * F, 2 * ch, q), e1 = r16::load_block(db + c * F, 2 * ch + 1, q);
-                if (ok) {
-                    r16::store_state<H16>(p.v, vo + c * F, 2 * ch, q, e0 + a0 * gg.b[2 * ch]);
-                    r16::store_state<H16>(p.v, vo + c * F, 2 * ch + 1, q, e1 + a1 * gg.b[2 * ch + 1]);
-                    r16::store_block(db + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
-                    r16::store_block(db + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
-                    r16::store_block(cb + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
-                    r16::store_block(cb + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
-                }
+            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+            r16::gemm_bt(a0, a1, vc, wl, lane);
+            a0 *= usc; a1 *= usc;
+            if (ok) {
+                r16::store_state<H16>(p.v, vo + c * F, 2 * ch, q, t.b[2 * ch] + a0 * gg.b[2 * ch]);
+                r16::store_state<H16>(p.v, vo + c * F, 2 * ch + 1, q, t.b[2 * ch + 1] + a1 * gg.b[2 * ch + 1]);
+                r16::store_block(db + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
+                r16::store_block(db + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
+                r16::store_block(cb + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
+                r16::store_block(cb + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
             }
             pipe.release();
         }
@@ -300,10 +302,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
         OP sn;
         float psc;
         {
-            A16 t;
-#pragma unroll
-            for (int nb = 0; nb < NBK; ++nb) t.b[nb] = r16::load_state<H16>(p.s, so_, nb, q);
-            psc = sn.set_scaled(t);
+            psc = sn.set_scaled(snew);               // the rows written above, still in registers
         }
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
@@ -375,7 +374,7 @@ static hipError_t set_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-static size_t update_lds_bytes(int NB) { return 4 * (size_t)256 * NB * 16 + 10 * (size_t)32 * NB * 4; }
+static size_t update_lds_bytes(int NB) { return 2 * update_superchunk(NB) * (size_t)256 * NB * 16 + 10 * (size_t)32 * NB * 4; }
 
 template <int NB, int WAVES>
 static hipError_t configure_nb()

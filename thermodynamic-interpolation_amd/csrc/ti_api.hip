@@ -380,7 +380,7 @@ void pack_painn(ti_handle* h, const float* wts)
             chunk16(h->upd[l].W2, F, 3 * F, 2 * F + 32 * nbo, 0);                     // add_invariant_features
         }
         layer16(h->upd[l].W2, F, 3 * F, 0);                                           // gates
-        layer16(h->U[l], F, F, 0);                                                    // phase C
+        for (int c = 0; c < 3; ++c) layer16(h->U[l], F, F, 0);                        // phase C (one spatial component per walk)
         if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);                            // phase D
         pad_even(o);                                                                  // whole superchunks
         h->st_update.push_back(end_stream(o));
