@@ -126,9 +126,9 @@ struct Pipe {
 // staging registers, no ds_write.  The DMA is issued when the first logical chunk of the current superchunk is released
 // (hipcc drains vmcnt(0) at the next use of an ordinary global load while a DMA is in flight, so it is kept away from
 // the GEMM prologues), and is waited for at the superchunk's closing barrier.
-template <int NB, int T, int SC>
+template <int NB, int T, int SC, int CHUNK4 = 256 * NB>      // CHUNK4: float4 per chunk (128 * NB for the hi-only chunks of the fp16 storage mode)
 struct PipeDMA {
-    static constexpr int CH4 = 256 * NB, SUP4 = CH4 * SC, PER = SUP4 / T;
+    static constexpr int CH4 = CHUNK4, SUP4 = CH4 * SC, PER = SUP4 / T;
     static_assert(SUP4 % T == 0, "superchunk must be a multiple of the workgroup's 16-byte lanes");
     const f32x4* __restrict__ g;
     f32x4* base;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK
 // ---------------------------------------------------------------------------------------------------------------------
 // fp16-storage mode (include/ti_hip.h TI_PREC_F16; BASELINE.json configs[4] "fp16 node features with MFMA linears"): the state
 // tensors s, v, P, e live in HBM as fp16, every matrix product is ONE v_mfma_f32_16x16x32_f16 per 32-wide k-step on the fp16
-// rounding of its operands (weights: the hi halves of the split image, the lo halves are simply not read), accumulation,
+// rounding of its operands (weights: a hi-only image, half the bytes per chunk through LDS), accumulation,
 // LayerNorm, SiLU, sin / cos and the per-atom sums stay fp32.  A separately labelled precision: its drift error against the
 // reference is ~1e-3, not the 1e-5 of the other two paths (tests/test_gpu_parity.py reports it).
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -758,7 +758,7 @@ __device__ __forceinline__ void gemm_half_chunk(f32x4& acc0, f32x4& acc1, const 
     f[0] = wl[lane];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-        if (s + 1 < STEPS) f[(s + 1) & 1] = wl[(2 * (s + 1)) * 64 + lane];          // hi fragment of the next step (the lo ones are skipped)
+        if (s + 1 < STEPS) f[(s + 1) & 1] = wl[(s + 1) * 64 + lane];                // the chunk holds hi fragments only (8 KB at F = 128)
         __builtin_amdgcn_sched_barrier(0x16);
         const int m = s % KS;
         f32x4& acc = s < KS ? acc0 : acc1;

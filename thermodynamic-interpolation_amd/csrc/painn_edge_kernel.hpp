@@ -38,22 +38,27 @@ __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p
 // the freed LDS holds 4-chunk superchunks (half the barriers; needs chunk counts % 4 == 0: 56/48/40/32) -- 1.8 % on the edge
 // kernel at B >= 32k.  Small launches keep 4 waves: fatter workgroups cost the latency regime 20-60 %.  F = 256 needs the
 // 512-register budget of one wave per SIMD and is always 4 waves.
-__host__ __device__ constexpr int edge_superchunk(int NB, int WAVES) { return (WAVES == 8 && NB == 4) ? 4 : 2; }
+// The fp16 storage mode streams hi-only chunks of half the size: at F = 128 it stages twice as many per barrier (same LDS bytes, half
+// the barriers; the chunk counts 56/48/40/32 divide by 8).
+__host__ __device__ constexpr int edge_superchunk(int NB, int WAVES, bool H16 = false) { return ((WAVES == 8 && NB == 4) ? 4 : 2) * (H16 && NB == 4 ? 2 : 1); }
+__host__ __device__ constexpr int edge_chunk4(int NB, bool H16) { return (H16 ? 128 : 256) * NB; }            // float4 per weight chunk
+// F = 32 in the storage mode: a 2-chunk superchunk (4 KB) is smaller than one 16-byte lane per thread of the 8-wave build
+__host__ __device__ constexpr bool edge_build_exists(int NB, int WAVES, int PREC) { return !(PREC == 2 && NB == 1 && WAVES == 8); }
 template <int NBK, bool FIRST, bool LAST, int PREC, int WAVES, int NS>
 __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
 {
-    constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = 256 * NB;
-    constexpr bool H16 = PREC == 2;                 // fp16 state tensors
+    constexpr bool H16 = PREC == 2;                 // fp16 state tensors, hi-only weight chunks
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = edge_chunk4(NB, H16);
     using A16 = r16::Act<NBK>;
     using OP = typename r16::OpSel<NBK, PREC>::type;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    constexpr int SC = edge_superchunk(NB, WAVES);                                  // weight chunks per barrier
+    constexpr int SC = edge_superchunk(NB, WAVES, H16);                             // weight chunks per barrier
     float* scratch = reinterpret_cast<float*>(lds + 2 * SC * CH4) + wave * 64;     // [16 rows][4] edge_dir of the block
     float* vec = reinterpret_cast<float*>(lds + 2 * SC * CH4) + WAVES * 64;        // [EV::COUNT][F]
     for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    PipeDMA<NB, T, SC> pipe;                                                     // weights staged SC chunks per barrier
+    PipeDMA<NB, T, SC, CH4> pipe;                                                // weights staged SC chunks per barrier
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);   // barrier inside: vec is visible after it
 
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
@@ -299,19 +304,22 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
 }
 
 // edge kernel LDS: two superchunks of two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors
-static size_t edge_lds_bytes(int NB, int WAVES) { return 2 * edge_superchunk(NB, WAVES) * (size_t)256 * NB * 16 + WAVES * 256 + 21 * (size_t)32 * NB * 4; }
+static size_t edge_lds_bytes(int NB, int WAVES, bool h16) { return 2 * edge_superchunk(NB, WAVES, h16) * (size_t)edge_chunk4(NB, h16) * 16 + WAVES * 256 + 21 * (size_t)32 * NB * 4; }
 
 
 template <int NB, int EW, int NS, int PREC>
 static hipError_t configure_edge_prec()
 {
-    const size_t be = edge_lds_bytes(NB, EW);
+    if constexpr (!edge_build_exists(NB, EW, PREC)) return hipSuccess;
+    else {
+    const size_t be = edge_lds_bytes(NB, EW, PREC == 2);
     hipError_t e;
     if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, false, PREC, EW, NS>, be)) != hipSuccess) return e;
     if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, false, PREC, EW, NS>, be)) != hipSuccess) return e;
     if ((e = set_lds_edge(painn_edge_kernel<2 * NB, false, true, PREC, EW, NS>, be)) != hipSuccess) return e;
     if ((e = set_lds_edge(painn_edge_kernel<2 * NB, true, true, PREC, EW, NS>, be)) != hipSuccess) return e;
     return hipSuccess;
+    }
 }
 template <int NB, int EW, int NS>
 static hipError_t configure_edge()
@@ -325,12 +333,14 @@ static hipError_t configure_edge()
 template <int NB, int EW, int NS, int PREC>
 static void launch_edge_p(bool first, bool last, const EdgeParams& p, hipStream_t st)
 {
+    if constexpr (edge_build_exists(NB, EW, PREC)) {
     const dim3 g((unsigned)((p.n_groups + EW - 1) / EW)), t(64 * EW);          // one wave (= one group or part) each
-    const size_t l = edge_lds_bytes(NB, EW);
+    const size_t l = edge_lds_bytes(NB, EW, PREC == 2);
     if (first && last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, true, PREC, EW, NS>), g, t, l, st, p);
     else if (first) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, true, false, PREC, EW, NS>), g, t, l, st, p);
     else if (last) hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, true, PREC, EW, NS>), g, t, l, st, p);
     else hipLaunchKernelGGL((painn_edge_kernel<2 * NB, false, false, PREC, EW, NS>), g, t, l, st, p);
+    }
 }
 template <int NB, int EW, int NS>
 static void launch_edge_w(bool first, bool last, int prec, const EdgeParams& p, hipStream_t st)
@@ -356,7 +366,7 @@ static hipError_t launch_edge_nb(bool first, bool last, int prec, const EdgePara
     if (p.max_slots > EDGE_MAX_SLOTS) return hipErrorInvalidValue;          // build_templates never produces such a block
     // 8-wave workgroups: split-fp16 path only (the f32 path is matrix-bound and loses 4 % to the wider barriers), enough groups to
     // fill every CU, and at most two destination atoms per row block (the only form the wide build is instantiated for)
-    const bool wide = NB <= 4 && prec != 0 && p.n_groups >= 2048 && p.max_slots <= 2;
+    const bool wide = NB <= 4 && prec != 0 && p.n_groups >= 2048 && p.max_slots <= 2 && edge_build_exists(NB, 8, prec);
     if constexpr (NB <= 4) { if (wide) { launch_edge_w<NB, 8, 2>(first, last, prec, p, st); return hipGetLastError(); } }
     if (p.max_slots <= 2) launch_edge_w<NB, 4, 2>(first, last, prec, p, st);
     else launch_edge_w<NB, 4, 4>(first, last, prec, p, st);

@@ -115,21 +115,23 @@ struct UV {                                         // per-layer vector block in
 
 // weight chunks per barrier.  4 (64 KB in flight per workgroup) was tried for the latency regime: no change (A = 9, B = 12: 59 vs 60 us),
 // the stream of a lone workgroup runs at the ~12 B/clk a CU gets from beyond L2, not at the number of bytes in flight
-__host__ __device__ constexpr int update_superchunk(int) { return 2; }
+// (the fp16 storage mode's hi-only chunks are half the size: four per barrier at F = 128, same LDS bytes)
+__host__ __device__ constexpr int update_superchunk(int NB, bool H16) { return H16 && NB == 4 ? 4 : 2; }
+__host__ __device__ constexpr int update_chunk4(int NB, bool H16) { return (H16 ? 128 : 256) * NB; }
 template <int NBK, bool HAS_NEXT, int PREC>
 __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(const UpdateParams p)
 {
-    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = 256 * NB;
-    constexpr bool H16 = PREC == 2;                 // s, v, P are fp16 in HBM (the accumulators stay fp32)
+    constexpr bool H16 = PREC == 2;                 // s, v, P are fp16 in HBM (the accumulators stay fp32), hi-only weight chunks
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = update_chunk4(NB, H16);
     using A16 = r16::Act<NBK>;
     using OP = typename r16::OpSel<NBK, PREC>::type;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    constexpr int SC = update_superchunk(NB);
+    constexpr int SC = update_superchunk(NB, H16);
     float* vec = reinterpret_cast<float*>(lds + 2 * SC * CH4);                     // [UV::COUNT][F]
     for (int i = threadIdx.x; i < UV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    PipeDMA<NB, T, SC> pipe;
+    PipeDMA<NB, T, SC, CH4> pipe;
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
     const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
@@ -374,7 +376,7 @@ static hipError_t set_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-static size_t update_lds_bytes(int NB) { return 2 * update_superchunk(NB) * (size_t)256 * NB * 16 + 10 * (size_t)32 * NB * 4; }
+static size_t update_lds_bytes(int NB, bool h16) { return 2 * update_superchunk(NB, h16) * (size_t)update_chunk4(NB, h16) * 16 + 10 * (size_t)32 * NB * 4; }
 
 template <int NB, int WAVES>
 static hipError_t configure_nb()
@@ -385,13 +387,13 @@ static hipError_t configure_nb()
     TI_SET((painn_embed_kernel<NB, WAVES, 2, false>)); TI_SET((painn_embed_kernel<NB, WAVES, 3, false>)); TI_SET((painn_embed_kernel<NB, WAVES, 4, false>));
     TI_SET((painn_embed_kernel<NB, WAVES, 2, true>)); TI_SET((painn_embed_kernel<NB, WAVES, 3, true>)); TI_SET((painn_embed_kernel<NB, WAVES, 4, true>));
     if ((e = (NB == 1 ? configure_edge_nb1() : NB == 2 ? configure_edge_nb2() : NB == 4 ? configure_edge_nb4() : configure_edge_nb8())) != hipSuccess) return e;
-    const size_t bu = update_lds_bytes(NB);
+    const size_t bu = update_lds_bytes(NB, false), bh = update_lds_bytes(NB, true);
     if ((e = set_lds(painn_update_kernel<2 * NB, true, 0>, bu)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, false, 0>, bu)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, true, 1>, bu)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, false, 1>, bu)) != hipSuccess) return e;
-    if ((e = set_lds(painn_update_kernel<2 * NB, true, 2>, bu)) != hipSuccess) return e;
-    if ((e = set_lds(painn_update_kernel<2 * NB, false, 2>, bu)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, true, 2>, bh)) != hipSuccess) return e;
+    if ((e = set_lds(painn_update_kernel<2 * NB, false, 2>, bh)) != hipSuccess) return e;
     TI_SET((painn_readout_kernel<NB, WAVES, false>)); TI_SET((painn_readout_kernel<NB, WAVES, true>));
 #undef TI_SET
     return hipSuccess;
@@ -457,7 +459,7 @@ hipError_t launch_update(int NBv, bool has_next, int prec, const UpdateParams& p
     TI_DISPATCH_NB(NBv, {
         (void)WAVES;
         const dim3 g((unsigned)((p.N + 63) / 64));                 // 4 waves x 16 atoms per workgroup
-        const size_t l = update_lds_bytes(NB);
+        const size_t l = update_lds_bytes(NB, prec == 2);
         if (prec == 2) {
             if (has_next) hipLaunchKernelGGL((painn_update_kernel<2 * NB, true, 2>), g, dim3(256), l, st, p);
             else hipLaunchKernelGGL((painn_update_kernel<2 * NB, false, 2>), g, dim3(256), l, st, p);

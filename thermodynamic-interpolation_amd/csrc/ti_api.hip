@@ -73,6 +73,22 @@ void pack_chunk16_split(std::vector<float>& dst, const float* W, int ld, int n_r
                 }
 }
 
+// fp16 storage mode (r16::OpndH): the hi fragments alone, half the bytes:  frag[(blk*(NBK/2) + m)*64 + l][i]
+void pack_chunk16_half(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBK)
+{
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)NBK * 64 * 4);
+    _Float16* out = reinterpret_cast<_Float16*>(dst.data() + base);
+    const int KS = NBK / 2;
+    for (int blk = 0; blk < 2; ++blk)
+        for (int m = 0; m < KS; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 8; ++i) {
+                    const int row = row0 + 16 * blk + (l & 15), col = col0 + 16 * (2 * m + (i >> 2)) + 4 * (l >> 4) + (i & 3);
+                    out[((size_t)(blk * KS + m) * 64 + l) * 8 + i] = (_Float16)(row < n_rows ? W[(size_t)row * ld + col] : 0.f);
+                }
+}
+
 struct MlpOff { size_t W0, b0, g0, be0, W1, b1, g1, be1, W2, b2; int f_in, f_h, f_out; };
 static size_t take_mlp(MlpOff& m, size_t o, int f_in, int f_h, int f_out)
 {
@@ -351,12 +367,16 @@ void pack_painn(ti_handle* h, const float* wts)
     else for (int nbo = 0; nbo < NB; ++nbo) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f);
     h->st_embed = end_stream(o);
     const int NBK = F / 16;
-    const bool split = h->d.precision != TI_PREC_F32;          // f16x2 and f16 read the (hi, lo) fp16 image (f16: the hi halves only)
+    const int prec = h->d.precision;          // 16-row chunks: f32 image, (hi, lo) fp16 image of the same size, or hi-only fp16 image of half the size
+    const size_t ch4 = (prec == TI_PREC_F16 ? 128 : 256) * (size_t)NB;      // float4 per 16-row chunk
     auto chunk16 = [&](size_t W, int ld, int n_rows, int row0, int col0) {
-        if (split) pack_chunk16_split(pk, wts + W, ld, n_rows, row0, col0, NBK); else pack_chunk16(pk, wts + W, ld, n_rows, row0, col0, NBK);
+        if (prec == TI_PREC_F16) pack_chunk16_half(pk, wts + W, ld, n_rows, row0, col0, NBK);
+        else if (prec == TI_PREC_F16X2) pack_chunk16_split(pk, wts + W, ld, n_rows, row0, col0, NBK);
+        else pack_chunk16(pk, wts + W, ld, n_rows, row0, col0, NBK);
     };
     auto layer16 = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) chunk16(W, ld, n_rows, 32 * nbo, col0); };
-    auto pad_even = [&](size_t off4) { if (((pk.size() / 4 - off4) / (256 * (size_t)NB)) % 2) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f); };
+    auto end_stream16 = [&](size_t off4) { return Stream{off4, (int)((pk.size() / 4 - off4) / ch4)}; };
+    auto pad_even = [&](size_t off4) { if (((pk.size() / 4 - off4) / ch4) % 2) pk.resize(pk.size() + 4 * ch4, 0.f); };
     for (int l = 0; l < L; ++l) {
         const bool first = l == 0, last = l == L - 1;
         o = begin_stream();                          // edge kernel: 16-row chunk format
@@ -370,7 +390,7 @@ void pack_painn(ti_handle* h, const float* wts)
                 chunk16(h->phi[l].W2, F, 5 * F, c * F + 32 * nbo, 0);
                 chunk16(h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0);
             }
-        h->st_edge.push_back(end_stream(o));
+        h->st_edge.push_back(end_stream16(o));
         o = begin_stream();                          // update kernel: 16-row chunk format, order of painn_update_kernel
         layer16(h->V[l], F, F, 0);                                                    // phase A (3 components per visit)
         layer16(h->upd[l].W0, 2 * F, F, 0); layer16(h->upd[l].W0, 2 * F, F, F);      // MLP L1: |vv| part, s part
@@ -383,7 +403,7 @@ void pack_painn(ti_handle* h, const float* wts)
         for (int c = 0; c < 3; ++c) layer16(h->U[l], F, F, 0);                        // phase C (one spatial component per walk)
         if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);                            // phase D
         pad_even(o);                                                                  // whole superchunks
-        h->st_update.push_back(end_stream(o));
+        h->st_update.push_back(end_stream16(o));
         // tangent edge kernel (painn_jvp_kernels.hip): the phi branch's chunks in the consumption order of the edge kernels
         for (int which = 1; which < 2; ++which) {      // the phi branch alone (the primal pass reads the primal edge stream)
             const MlpOff& m = h->phi[l];
@@ -396,9 +416,9 @@ void pack_painn(ti_handle* h, const float* wts)
                     if ((c == 0 || c == 4) && first) continue;
                     chunk16(m.W2, F, 5 * F, c * F + 32 * nbo, 0);
                 }
-            const int real = end_stream(o).nch;   // an odd count gets one pad chunk, which the kernels swallow once per row block
+            const int real = end_stream16(o).nch;   // an odd count gets one pad chunk, which the kernels swallow once per row block
             pad_even(o);
-            h->st_jvp_phi.push_back(end_stream(o));
+            h->st_jvp_phi.push_back(end_stream16(o));
             h->jvp_phi_pad.push_back(real & 1);
         }
         o = begin_stream();                          // tangent update kernel: same order, V and U once per spatial component
@@ -413,7 +433,7 @@ void pack_painn(ti_handle* h, const float* wts)
         for (int c = 0; c < 3; ++c) layer16(h->U[l], F, F, 0);
         if (!last) layer16(h->phi[l + 1].W0, 2 * F, F, 0);
         pad_even(o);
-        h->st_jvp_update.push_back(end_stream(o));
+        h->st_jvp_update.push_back(end_stream16(o));
     }
     o = begin_stream();
     layer(h->readout.W0, F, F, 0); layer(h->readout.W1, F, F, 0);
@@ -425,7 +445,7 @@ void pack_painn(ti_handle* h, const float* wts)
             chunk16(Wm, F, F, 32 * nbo, 0);
         }
     pad_even(o);
-    h->st_jvp_readout = end_stream(o);
+    h->st_jvp_readout = end_stream16(o);
     h->packed.upload(pk);
     {
         std::vector<float> rv;                       // order = struct RV in painn_jvp_kernels.hip
