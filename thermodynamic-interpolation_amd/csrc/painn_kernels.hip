@@ -23,87 +23,6 @@ hipError_t configure_edge_nb1(); hipError_t configure_edge_nb2(); hipError_t con
 hipError_t launch_edge_nb1(bool, bool, int, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb2(bool, bool, int, const EdgeParams&, hipStream_t);
 hipError_t launch_edge_nb4(bool, bool, int, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb8(bool, bool, int, const EdgeParams&, hipStream_t);
 
-template <int NB, int WAVES>
-struct Cfg {
-    static constexpr int F = 32 * NB;
-    static constexpr int T = 64 * WAVES;
-    static constexpr int CH4 = 256 * NB;
-    static constexpr size_t lds_bytes = 2 * (size_t)CH4 * 16;     // node kernels: the two weight chunk buffers
-};
-
-// ================================================================================================== embed kernel
-// s = MLP([atom_emb | enc(T0) | enc(T1) | enc(t)]),  P = s @ phi0.W0[:, :F]^T + phi0.b0
-template <int NB, int WAVES, int NSEG, bool H16>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_embed_kernel(const EmbedParams p)
-{
-    using C = Cfg<NB, WAVES>;
-    constexpr int F = C::F;
-    extern __shared__ f32x4 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5;
-    Pipe<NB, C::T> pipe;
-    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);
-
-    const long long node = ((long long)blockIdx.x * WAVES + wave) * 32 + j;
-    const bool ok = node < p.N;
-    const long long nd = ok ? node : p.N - 1;
-
-    Act<NB> acc;
-#pragma unroll
-    for (int nbo = 0; nbo < NB; ++nbo) acc.b[nbo] = load_block(p.mlp.b0, nbo, h);
-#pragma unroll
-    for (int seg = 0; seg < NSEG; ++seg) {
-        Act<NB> in;
-        if (seg == 0) {
-            load_set(in, p.atom_emb + (size_t)p.atom_ids[nd % p.A] * F, h);
-        } else if (seg < NSEG - 1) {
-            // TemperatureEncoder.forward: (T - mean(temps)) / (max - min), then PositionalEncoder(max_length=temp_length)
-            float u = p.cond[nd * p.ncond + (seg - 1)] - p.temp_mean;
-            u = u / p.temp_range;
-            posenc_set(in, u / p.temp_length, h);
-        } else {
-            posenc_set(in, p.t / p.time_length, h);      // batch.t = t * ones_like(atoms)
-        }
-#pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) {
-            const f32x4* wl = pipe.begin();
-            gemm_bt(acc.b[nbo], in, wl, lane);
-            pipe.end();
-        }
-    }
-    ln_silu(acc, p.mlp.g0, p.mlp.be0, h);
-    Act<NB> h2;
-#pragma unroll
-    for (int nbo = 0; nbo < NB; ++nbo) {
-        const f32x4* wl = pipe.begin();
-        f32x16 a = load_block(p.mlp.b1, nbo, h);
-        gemm_bt(a, acc, wl, lane);
-        h2.b[nbo] = a;
-        pipe.end();
-    }
-    ln_silu(h2, p.mlp.g1, p.mlp.be1, h);
-    Act<NB> sset;
-#pragma unroll
-    for (int nbo = 0; nbo < NB; ++nbo) {
-        const f32x4* wl = pipe.begin();
-        f32x16 a = load_block(p.mlp.b2, nbo, h);
-        gemm_bt(a, h2, wl, lane);
-        sset.b[nbo] = a;
-        pipe.end();
-    }
-    if (ok) {
-#pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) store_block_t<H16>(p.s, (size_t)node * F, nbo, h, sset.b[nbo]);
-    }
-#pragma unroll
-    for (int nbo = 0; nbo < NB; ++nbo) {
-        const f32x4* wl = pipe.begin();
-        f32x16 a = load_block(p.pb0, nbo, h);
-        gemm_bt(a, sset, wl, lane);
-        pipe.end();
-        if (ok) store_block_t<H16>(p.P, (size_t)node * F, nbo, h, a);
-    }
-}
-
 // ================================================================================================== update kernel
 // v <- v + dv  with  dv = dvacc + cacc x v   (the cross product with v[dst] factors out of the edge sum),
 // s <- s + dsacc, then Update.forward (cpainn.py:345-376); finally P for the next layer's message block.
@@ -319,53 +238,181 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
     pipe.drain();
 }
 
-// ================================================================================================== readout kernel
-template <int NB, int WAVES, bool H16>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void painn_readout_kernel(const ReadoutParams p)
+// ================================================================================================== embed / readout kernels
+// embed:   s = MLP([atom_emb | enc(T0) | enc(T1) | enc(t)]),  P = s @ phi0.W0[:, :F]^T + phi0.b0
+// readout: gate(MLP(s)) * (Vr . v)
+// 16 atoms per wave on the r16 primitives and the precision's matrix path (f32 16x16x4, split fp16, fp16).  (Until round 2 these two ran
+// 32 rows per wave on the f32 32x32x2 MFMA whatever the precision: a lone wave spent 1.8 us per weight chunk there against 0.3 us here,
+// which is what a small batch pays -- 80 + 35 us of a 620 us evaluation of 12 molecules.)
+template <int NBK, int NSEG, int PREC>
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_embed16_kernel(const EmbedParams p)
 {
-    using C = Cfg<NB, WAVES>;
-    constexpr int F = C::F;
+    constexpr bool H16 = PREC == 2;
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = update_chunk4(NB, H16);
+    using A16 = r16::Act<NBK>;
+    using OP = typename r16::OpSel<NBK, PREC>::type;
     extern __shared__ f32x4 lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5;
-    Pipe<NB, C::T> pipe;
-    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds);
-    const long long node = ((long long)blockIdx.x * WAVES + wave) * 32 + j;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    PipeDMA<NB, T, 2, CH4> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+    const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
+    const bool ok = node < p.N;
+    const long long nd = ok ? node : p.N - 1;
+
+    A16 acc;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) acc.b[nb] = r16::load_block(p.mlp.b0, nb, q);
+#pragma unroll
+    for (int seg = 0; seg < NSEG; ++seg) {
+        OP op;
+        float sc = 1.0f;
+        {
+            A16 in;
+            if (seg == 0) {
+                r16::load_set(in, p.atom_emb + (size_t)p.atom_ids[nd % p.A] * F, q);
+                sc = op.set_scaled(in);                          // an embedding table: any magnitude
+            } else if (seg < NSEG - 1) {
+                // TemperatureEncoder.forward: (T - mean(temps)) / (max - min), then PositionalEncoder(max_length=temp_length)
+                float u = p.cond[nd * p.ncond + (seg - 1)] - p.temp_mean;
+                u = u / p.temp_range;
+                r16::posenc_set(in, u / p.temp_length, q);
+                op.set(in);
+            } else {
+                r16::posenc_set(in, p.t / p.time_length, q);     // batch.t = t * ones_like(atoms)
+                op.set(in);
+            }
+        }
+        const float inv = r16::pow2_inverse(sc);
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = acc.b[2 * ch] * inv, a1 = acc.b[2 * ch + 1] * inv;     // exact: sc is a power of two
+            r16::gemm_bt(a0, a1, op, wl, lane);
+            acc.b[2 * ch] = a0 * sc; acc.b[2 * ch + 1] = a1 * sc;
+            pipe.release();
+        }
+    }
+    r16::ln_silu(acc, p.mlp.g0, p.mlp.be0, q);
+    A16 t;
+    {
+        OP h1;
+        h1.set(acc);
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(p.mlp.b1, 2 * ch, q), a1 = r16::load_block(p.mlp.b1, 2 * ch + 1, q);
+            r16::gemm_bt(a0, a1, h1, wl, lane);
+            t.b[2 * ch] = a0; t.b[2 * ch + 1] = a1;
+            pipe.release();
+        }
+    }
+    r16::ln_silu(t, p.mlp.g1, p.mlp.be1, q);
+    A16 sset;
+    {
+        OP h2;
+        h2.set(t);
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(p.mlp.b2, 2 * ch, q), a1 = r16::load_block(p.mlp.b2, 2 * ch + 1, q);
+            r16::gemm_bt(a0, a1, h2, wl, lane);
+            sset.b[2 * ch] = a0; sset.b[2 * ch + 1] = a1;
+            pipe.release();
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) r16::store_state<H16>(p.s, (size_t)node * F, nb, q, sset.b[nb]);
+    }
+    {
+        OP sn;
+        const float psc = sn.set_scaled(sset), pinv = r16::pow2_inverse(psc);
+#pragma unroll
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(p.pb0, 2 * ch, q) * pinv, a1 = r16::load_block(p.pb0, 2 * ch + 1, q) * pinv;
+            r16::gemm_bt(a0, a1, sn, wl, lane);
+            pipe.release();
+            if (ok) {
+                r16::store_state<H16>(p.P, (size_t)node * F, 2 * ch, q, a0 * psc);
+                r16::store_state<H16>(p.P, (size_t)node * F, 2 * ch + 1, q, a1 * psc);
+            }
+        }
+    }
+    pipe.drain();
+}
+
+template <int NBK, int PREC>
+__global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_readout16_kernel(const ReadoutParams p)
+{
+    constexpr bool H16 = PREC == 2;
+    constexpr int F = 16 * NBK, NB = (F + 31) / 32, WAVES = 4, T = 64 * WAVES, CH4 = update_chunk4(NB, H16);
+    using A16 = r16::Act<NBK>;
+    using OP = typename r16::OpSel<NBK, PREC>::type;
+    extern __shared__ f32x4 lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    PipeDMA<NB, T, 2, CH4> pipe;
+    pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
+    const long long node = ((long long)blockIdx.x * WAVES + wave) * 16 + j;
     const bool ok = node < p.N;
     const size_t nd = (size_t)(ok ? node : p.N - 1);
 
-    Act<NB> h1, h2;
+    A16 h1;
     {
-        Act<NB> ss;
+        OP sop;
+        float ssc;
+        {
+            A16 ss;
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) ss.b[nbo] = load_block_t<H16>(p.s, nd * F, nbo, h);
+            for (int nb = 0; nb < NBK; ++nb) ss.b[nb] = r16::load_state<H16>(p.s, nd * F, nb, q);
+            ssc = sop.set_scaled(ss);
+        }
+        const float sinv = r16::pow2_inverse(ssc);
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) {
-            const f32x4* wl = pipe.begin();
-            f32x16 a = load_block(p.mlp.b0, nbo, h);
-            gemm_bt(a, ss, wl, lane);
-            h1.b[nbo] = a;
-            pipe.end();
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(p.mlp.b0, 2 * ch, q) * sinv, a1 = r16::load_block(p.mlp.b0, 2 * ch + 1, q) * sinv;
+            r16::gemm_bt(a0, a1, sop, wl, lane);
+            h1.b[2 * ch] = a0 * ssc; h1.b[2 * ch + 1] = a1 * ssc;
+            pipe.release();
         }
     }
-    ln_silu(h1, p.mlp.g0, p.mlp.be0, h);
+    r16::ln_silu(h1, p.mlp.g0, p.mlp.be0, q);
+    A16 h2;
+    {
+        OP o1;
+        o1.set(h1);
 #pragma unroll
-    for (int nbo = 0; nbo < NB; ++nbo) {
-        const f32x4* wl = pipe.begin();
-        f32x16 a = load_block(p.mlp.b1, nbo, h);
-        gemm_bt(a, h1, wl, lane);
-        h2.b[nbo] = a;
-        pipe.end();
+        for (int ch = 0; ch < NB; ++ch) {
+            const f32x4* wl = pipe.acquire();
+            f32x4 a0 = r16::load_block(p.mlp.b1, 2 * ch, q), a1 = r16::load_block(p.mlp.b1, 2 * ch + 1, q);
+            r16::gemm_bt(a0, a1, o1, wl, lane);
+            h2.b[2 * ch] = a0; h2.b[2 * ch + 1] = a1;
+            pipe.release();
+        }
     }
-    ln_silu(h2, p.mlp.g1, p.mlp.be1, h);
-    // split(mlp(s), 1): [invariant_out (unused by cPaiNN.forward), gates]
-    const float gate = dot_set(h2, p.w2_gate, h) + p.b2_gate;
+    pipe.drain();
+    r16::ln_silu(h2, p.mlp.g1, p.mlp.be1, q);
+    // split(mlp(s), 1): [invariant_out (unused by cPaiNN.forward), gates]; the 1-row output layers are dot products over the features
+    float gate = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+        const f32x4 w = r16::load_block(p.w2_gate, nb, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gate += h2.b[nb][r] * w[r];
+    }
+    gate = r16::xquarters(gate) + p.b2_gate;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        Act<NB> vc;
+        float vv = 0.f;
 #pragma unroll
-        for (int nbo = 0; nbo < NB; ++nbo) vc.b[nbo] = load_block_t<H16>(p.v, (nd * 3 + c) * F, nbo, h);
-        const float vv = dot_set(vc, p.Vr, h);
-        if (ok && h == 0) p.out[node * 3 + c] = vv * gate;
+        for (int nb = 0; nb < NBK; ++nb) {
+            const f32x4 x = r16::load_state<H16>(p.v, (nd * 3 + c) * F, nb, q), w = r16::load_block(p.Vr, nb, q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv += x[r] * w[r];
+        }
+        vv = r16::xquarters(vv);
+        if (ok && q == 0) p.out[node * 3 + c] = vv * gate;
     }
 }
 
@@ -381,11 +428,22 @@ static size_t update_lds_bytes(int NB, bool h16) { return 2 * update_superchunk(
 template <int NB, int WAVES>
 static hipError_t configure_nb()
 {
-    const size_t b = Cfg<NB, WAVES>::lds_bytes;
     hipError_t e;
-#define TI_SET(k) if ((e = set_lds(k, b)) != hipSuccess) return e
-    TI_SET((painn_embed_kernel<NB, WAVES, 2, false>)); TI_SET((painn_embed_kernel<NB, WAVES, 3, false>)); TI_SET((painn_embed_kernel<NB, WAVES, 4, false>));
-    TI_SET((painn_embed_kernel<NB, WAVES, 2, true>)); TI_SET((painn_embed_kernel<NB, WAVES, 3, true>)); TI_SET((painn_embed_kernel<NB, WAVES, 4, true>));
+    {
+        const size_t n0 = 2 * 2 * (size_t)update_chunk4(NB, false) * 16, n2 = 2 * 2 * (size_t)update_chunk4(NB, true) * 16;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 2, 0>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 3, 0>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 4, 0>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 2, 1>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 3, 1>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 4, 1>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 2, 2>, n2)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 3, 2>, n2)) != hipSuccess) return e;
+        if ((e = set_lds(painn_embed16_kernel<2 * NB, 4, 2>, n2)) != hipSuccess) return e;
+        if ((e = set_lds(painn_readout16_kernel<2 * NB, 0>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_readout16_kernel<2 * NB, 1>, n0)) != hipSuccess) return e;
+        if ((e = set_lds(painn_readout16_kernel<2 * NB, 2>, n2)) != hipSuccess) return e;
+    }
     if ((e = (NB == 1 ? configure_edge_nb1() : NB == 2 ? configure_edge_nb2() : NB == 4 ? configure_edge_nb4() : configure_edge_nb8())) != hipSuccess) return e;
     const size_t bu = update_lds_bytes(NB, false), bh = update_lds_bytes(NB, true);
     if ((e = set_lds(painn_update_kernel<2 * NB, true, 0>, bu)) != hipSuccess) return e;
@@ -394,8 +452,7 @@ static hipError_t configure_nb()
     if ((e = set_lds(painn_update_kernel<2 * NB, false, 1>, bu)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, true, 2>, bh)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, false, 2>, bh)) != hipSuccess) return e;
-    TI_SET((painn_readout_kernel<NB, WAVES, false>)); TI_SET((painn_readout_kernel<NB, WAVES, true>));
-#undef TI_SET
+
     return hipSuccess;
 }
 
@@ -421,24 +478,27 @@ hipError_t configure_painn_kernels(int NBv)
     return hipSuccess;
 }
 
-template <int NB, int WAVES>
-static dim3 node_grid(long long N) { return dim3((unsigned)((N + 32LL * WAVES - 1) / (32LL * WAVES))); }
 
 // prec: include/ti_hip.h TI_PREC_* (0 f32, 1 f16x2, 2 f16 storage mode: the state tensors are fp16)
+static size_t node16_lds_bytes(int NB, bool h16) { return 2 * 2 * (size_t)update_chunk4(NB, h16) * 16; }      // PipeDMA<.., SC = 2>: two superchunks
+
+template <int NB, int PREC>
+static void launch_embed16(int nseg, const EmbedParams& p, hipStream_t st)
+{
+    const dim3 g((unsigned)((p.N + 63) / 64));                 // 4 waves x 16 atoms per workgroup
+    const size_t l = node16_lds_bytes(NB, PREC == 2);
+    if (nseg == 4) hipLaunchKernelGGL((painn_embed16_kernel<2 * NB, 4, PREC>), g, dim3(256), l, st, p);
+    else if (nseg == 3) hipLaunchKernelGGL((painn_embed16_kernel<2 * NB, 3, PREC>), g, dim3(256), l, st, p);
+    else hipLaunchKernelGGL((painn_embed16_kernel<2 * NB, 2, PREC>), g, dim3(256), l, st, p);
+}
+
 hipError_t launch_embed(int NBv, int nseg, int prec, const EmbedParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
-        const dim3 g = node_grid<NB, WAVES>(p.N);
-        const size_t l = Cfg<NB, WAVES>::lds_bytes;
-        if (prec == 2) {
-            if (nseg == 4) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 4, true>), g, dim3(64 * WAVES), l, st, p);
-            else if (nseg == 3) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 3, true>), g, dim3(64 * WAVES), l, st, p);
-            else hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 2, true>), g, dim3(64 * WAVES), l, st, p);
-        } else {
-            if (nseg == 4) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 4, false>), g, dim3(64 * WAVES), l, st, p);
-            else if (nseg == 3) hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 3, false>), g, dim3(64 * WAVES), l, st, p);
-            else hipLaunchKernelGGL((painn_embed_kernel<NB, WAVES, 2, false>), g, dim3(64 * WAVES), l, st, p);
-        }
+        (void)WAVES;
+        if (prec == 2) launch_embed16<NB, 2>(nseg, p, st);
+        else if (prec == 1) launch_embed16<NB, 1>(nseg, p, st);
+        else launch_embed16<NB, 0>(nseg, p, st);
     });
     return hipGetLastError();
 }
@@ -477,10 +537,12 @@ hipError_t launch_update(int NBv, bool has_next, int prec, const UpdateParams& p
 hipError_t launch_readout(int NBv, int prec, const ReadoutParams& p, hipStream_t st)
 {
     TI_DISPATCH_NB(NBv, {
-        const dim3 g = node_grid<NB, WAVES>(p.N);
-        const size_t l = Cfg<NB, WAVES>::lds_bytes;
-        if (prec == 2) hipLaunchKernelGGL((painn_readout_kernel<NB, WAVES, true>), g, dim3(64 * WAVES), l, st, p);
-        else hipLaunchKernelGGL((painn_readout_kernel<NB, WAVES, false>), g, dim3(64 * WAVES), l, st, p);
+        (void)WAVES;
+        const dim3 g((unsigned)((p.N + 63) / 64));
+        const size_t l = node16_lds_bytes(NB, prec == 2);
+        if (prec == 2) hipLaunchKernelGGL((painn_readout16_kernel<2 * NB, 2>), g, dim3(256), l, st, p);
+        else if (prec == 1) hipLaunchKernelGGL((painn_readout16_kernel<2 * NB, 1>), g, dim3(256), l, st, p);
+        else hipLaunchKernelGGL((painn_readout16_kernel<2 * NB, 0>), g, dim3(256), l, st, p);
     });
     return hipGetLastError();
 }

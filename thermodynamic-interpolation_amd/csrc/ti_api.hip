@@ -24,19 +24,6 @@ struct HipError : std::runtime_error { using std::runtime_error::runtime_error; 
     throw HipError(std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
 // ---------------------------------------------------------------------------------------------------- packing
-void pack_chunk(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBin)
-{
-    const size_t base = dst.size();
-    dst.resize(base + (size_t)NBin * 16 * 64);
-    for (int nbi = 0; nbi < NBin; ++nbi)
-        for (int g = 0; g < 4; ++g)
-            for (int l = 0; l < 64; ++l)
-                for (int q = 0; q < 4; ++q) {
-                    const int row = row0 + (l & 31), col = col0 + 32 * nbi + 8 * g + 4 * (l >> 5) + q;
-                    dst[base + ((size_t)(nbi * 4 + g) * 64 + l) * 4 + q] = row < n_rows ? W[(size_t)row * ld + col] : 0.f;
-                }
-}
-
 // 16-row kernels (mfma_chain.hpp, namespace r16): chunk[(blk*NBK + nbi)*64 + l][r] = W[row0 + 16*blk + (l&15)][col0 + 16*nbi + 4*(l>>4) + r]
 void pack_chunk16(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBK)
 {
@@ -133,7 +120,7 @@ struct ti_handle {
     int NB = 0, nE = 0, ncond = 0, G = 1, nblk = 0;
     MlpOff embed{}, readout{}; std::vector<MlpOff> phi, w, upd; std::vector<size_t> U, V;
     size_t edge_emb = 0, atom_emb = 0, Vr = 0; float b2_gate = 0.f;
-    Stream st_embed{}, st_readout{}; std::vector<Stream> st_edge, st_update;
+    Stream st_embed16{}; std::vector<Stream> st_edge, st_update;
     // edge templates (ti_internal.hpp): [0] throughput (G molecules per group), [1] latency (G = 1, P parts per molecule);
     // G / P / nblk / rows / slotnode below are those of the ACTIVE one (select_template, once per API call)
     struct Tpl {
@@ -357,15 +344,7 @@ void pack_painn(ti_handle* h, const float* wts)
     const int F = h->d.n_features, L = h->d.n_layers, NB = h->NB, nE = h->nE;
     std::vector<float> pk;
     auto begin_stream = [&]() { return pk.size() / 4; };
-    auto end_stream = [&](size_t off4) { return Stream{off4, (int)((pk.size() / 4 - off4) / (256 * (size_t)NB))}; };
-    auto layer = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) pack_chunk(pk, wts + W, ld, n_rows, 32 * nbo, col0, NB); };
-    // embed: L1 by input segment, L2, L3, then P for the first message block
-    size_t o = begin_stream();
-    for (int seg = 0; seg < nE; ++seg) layer(h->embed.W0, nE * F, F, seg * F);
-    layer(h->embed.W1, F, F, 0); layer(h->embed.W2, F, F, 0);
-    if (L > 0) layer(h->phi[0].W0, 2 * F, F, 0);
-    else for (int nbo = 0; nbo < NB; ++nbo) pk.resize(pk.size() + 1024 * (size_t)NB, 0.f);
-    h->st_embed = end_stream(o);
+    size_t o = 0;
     const int NBK = F / 16;
     const int prec = h->d.precision;          // 16-row chunks: f32 image, (hi, lo) fp16 image of the same size, or hi-only fp16 image of half the size
     const size_t ch4 = (prec == TI_PREC_F16 ? 128 : 256) * (size_t)NB;      // float4 per 16-row chunk
@@ -377,6 +356,13 @@ void pack_painn(ti_handle* h, const float* wts)
     auto layer16 = [&](size_t W, int ld, int n_rows, int col0) { for (int nbo = 0; nbo < NB; ++nbo) chunk16(W, ld, n_rows, 32 * nbo, col0); };
     auto end_stream16 = [&](size_t off4) { return Stream{off4, (int)((pk.size() / 4 - off4) / ch4)}; };
     auto pad_even = [&](size_t off4) { if (((pk.size() / 4 - off4) / ch4) % 2) pk.resize(pk.size() + 4 * ch4, 0.f); };
+    o = begin_stream();                              // embed kernel, 16-row chunk format: L1 by input segment, L2, L3, then P for the first message block
+    for (int seg = 0; seg < nE; ++seg) layer16(h->embed.W0, nE * F, F, seg * F);
+    layer16(h->embed.W1, F, F, 0); layer16(h->embed.W2, F, F, 0);
+    if (L > 0) layer16(h->phi[0].W0, 2 * F, F, 0);
+    else pk.resize(pk.size() + 4 * ch4 * NB, 0.f);
+    pad_even(o);
+    h->st_embed16 = end_stream16(o);
     for (int l = 0; l < L; ++l) {
         const bool first = l == 0, last = l == L - 1;
         o = begin_stream();                          // edge kernel: 16-row chunk format
@@ -435,10 +421,7 @@ void pack_painn(ti_handle* h, const float* wts)
         pad_even(o);
         h->st_jvp_update.push_back(end_stream16(o));
     }
-    o = begin_stream();
-    layer(h->readout.W0, F, F, 0); layer(h->readout.W1, F, F, 0);
-    h->st_readout = end_stream(o);
-    // tangent readout kernel: 16-row chunk format
+    // readout kernels (primal and tangent): 16-row chunk format
     o = begin_stream();
     for (size_t Wm : {h->readout.W0, h->readout.W1})
         for (int nbo = 0; nbo < NB; ++nbo) {
@@ -565,7 +548,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     HIP_CHECK(hipMemsetAsync(h->dsacc.p, 0, (size_t)N * F * sizeof(float), st));
     {
         EmbedParams p{};
-        p.stream = h->S(h->st_embed); p.nch = h->st_embed.nch; p.mlp = h->vec(h->embed);
+        p.stream = h->S(h->st_embed16); p.nch = h->st_embed16.nch; p.mlp = h->vec(h->embed);
         p.pb0 = L > 0 ? h->F(h->phi[0].b0) : h->F(h->embed.b2);
         p.atom_emb = h->F(h->atom_emb); p.atom_ids = h->atom_ids.p; p.cond = cond_dev; p.ncond = h->ncond; p.A = A; p.N = N;
         p.t = t; p.temp_length = h->d.temp_length; p.time_length = h->d.time_length; p.temp_mean = h->d.temp_mean; p.temp_range = h->d.temp_range;
@@ -642,7 +625,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     }
     {
         ReadoutParams p{};
-        p.stream = h->S(h->st_readout); p.nch = h->st_readout.nch; p.mlp = h->vec(h->readout);
+        p.stream = h->S(h->st_jvp_readout); p.nch = h->st_jvp_readout.nch; p.mlp = h->vec(h->readout);      // the 16-row image of W0, W1
         p.w2_gate = h->F(h->readout.W2 + F); p.b2_gate = h->b2_gate; p.Vr = h->F(h->Vr);
         p.N = N; p.s = h->s.p; p.v = h->v.p; p.out = out_dev;
         Timed tm(h, TI_KERNEL_PAINN_READOUT);

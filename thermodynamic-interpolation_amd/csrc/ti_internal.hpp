@@ -174,10 +174,4 @@ hipError_t launch_interp_fit(float* coef /*[5][n]*/, const float* y0, const floa
                              float dt, long long n, hipStream_t st);
 hipError_t launch_interp_eval(float* out, const float* coef, float x, long long n, hipStream_t st);
 
-// ---- host-side weight packing (pack.cpp)
-// One chunk = 32 output rows [row0, row0+32) x F_in = 32*NBin input columns [col0, col0+F_in) of a row-major W[out][ld],
-// laid out [k-step/4][lane][4]:  chunk[(4*nbi+g)*64 + l][q] = W[row0 + (l&31)][col0 + 32*nbi + 8*g + 4*(l>>5) + q].
-// Rows >= n_rows are zero-filled.
-void pack_chunk(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBin);
-
 }  // namespace ti
