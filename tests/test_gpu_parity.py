@@ -114,9 +114,12 @@ def test_em_eps0_is_euler_bit_for_bit_and_noise_matches_oracle():
     np.testing.assert_array_equal(full[:, 1:], part)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x2", "f16"])
 @pytest.mark.parametrize("F,L,A,B,variant", [(64, 2, 18, 37, 0), (128, 2, 18, 130, 0), (256, 2, 25, 9, 1), (32, 5, 3, 200, 2), (128, 1, 2, 5, 0)])
-def test_painn_ragged_batches_vs_oracle(F, L, A, B, variant):
-    """Batch sizes that are not multiples of the molecule-group size or of the 32-row tiles; F = 64 and 256 paths."""
+def test_painn_ragged_batches_vs_oracle(F, L, A, B, variant, precision):
+    """Batch sizes that are not multiples of the molecule-group size or of the 16-row tiles; every feature width (its own chunk size and
+    superchunk depth per precision) on every matrix path.  The fp16 storage mode is held to its own bar."""
+    DRIFT_TOL = 1e-2 if precision == "f16" else globals()["DRIFT_TOL"]
     ti = pkg()
     syn, W = ti.synthetic, ti.weights
     src, dst, et = syn.fully_connected_template(A)
@@ -124,7 +127,7 @@ def test_painn_ragged_batches_vs_oracle(F, L, A, B, variant):
     x = syn.molecule_coords(B, A, seed=B)
     cond = [syn.ambient_cond(B, A), syn.latent_cond(B, A, 500.0), None][variant]
     kw = dict(temp_length=100.0 if variant == 0 else 75.0)
-    eng = ti.engine.PainnEngine(variant, F, L, A, src, dst, et, np.arange(A), flat, **kw)
+    eng = ti.engine.PainnEngine(variant, F, L, A, src, dst, et, np.arange(A), flat, precision=precision, **kw)
     orc = oracle.PainnOracle(variant, F, L, A, src, dst, et, np.arange(A), flat, **kw)
     got = eng.drift(x, 0.37, cond)
     assert rel_l2(got, orc.drift(x, 0.37, cond)) < DRIFT_TOL
