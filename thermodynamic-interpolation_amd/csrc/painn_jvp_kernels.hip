@@ -321,14 +321,16 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
         uint32_t mi[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) mi[r] = rows[blk * 16 + 4 * q + r];
-        f32x4 sel;
-        int snode[4];
+        // per-atom sums over the block's rows on VALU lane swaps (r16::QuarterSum; a block has at most 4 destination atoms): quarter q
+        // of the wave ends up with the 16-row sum of slot q, one atomic instruction per 16-feature half adds every slot of the block
+        r16::QuarterSum<4> qs;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sel[r] = (row_slot(mi[r]) == j) ? 1.0f : 0.0f;
-            const int sn = slotnode[blk * 16 + 4 * q + r];
+        for (int r = 0; r < 4; ++r) qs.set_row(r, row_slot(mi[r]));
+        int qnode;
+        {
+            const int sn = slotnode[blk * 16 + q];
             const long long m2 = sn >> 8;
-            snode[r] = (sn >= 0 && group_ok && mg * p.G + m2 < p.B) ? (int)((vmg * p.G + m2) * p.A + (sn & 255)) : -1;     // TANGENT node
+            qnode = (sn >= 0 && group_ok && mg * p.G + m2 < p.B) ? (int)((vmg * p.G + m2) * p.A + (sn & 255)) : -1;     // TANGENT node
         }
         f32x4 dir[4], tdir[4], dd;
 #pragma unroll
@@ -350,12 +352,8 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
             d0 = ta0 * B0 + A0 * (dd * Q0); d1 = ta1 * B1 + A1 * (dd * Q1);
         };
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
-            // f32 products: with the fp16 form (select_sum<true>) hipcc needs 346 registers for this kernel (824 spilled at two
-            // waves per SIMD), although the same call costs the primal edge kernel nothing
-            const f32x4 s0 = r16::select_sum<false>(sel, v0), s1 = r16::select_sum<false>(sel, v1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (snode[r] >= 0) { float* d = dst + (size_t)snode[r] * stride; add_noret(d, s0[r]); add_noret(d + 16, s1[r]); }
+            const float z0 = qs.sum(v0), z1 = qs.sum(v1);
+            if (qnode >= 0) { float* d = dst + (size_t)qnode * stride; add_noret(d, z0); add_noret(d + 16, z1); }
         };
 
 #pragma unroll 1
