@@ -492,3 +492,39 @@ def test_fp16_storage_mode_refuses_what_it_does_not_cover():
         eng.rollout_dlogp(g["x"], g["cond"], g["traj_grid"], scheme="euler")
     with pytest.raises(ti._lib.TiError):
         eng.jvp(g["x"], np.ones_like(g["x"]), 0.25, g["cond"])
+
+
+def test_fp16_storage_mode_reports_state_overflow():
+    """A state beyond the fp16 range (the range_big fixture drives v to 1e5 .. 1e6) cannot be stored in this mode: the rollout must
+    come back with TI_E_NAN, not with numbers."""
+    g = load_golden("range_big_f128")
+    ti = pkg()
+    eng = ti.engine.PainnEngine(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                                g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"],
+                                precision="f16")
+    with pytest.raises(ti._lib.TiError) as ei:
+        eng.rollout(g["x"], g["cond"], ti.engine.time_grid(0.0, 1.0, 3), scheme="euler", save_every=0)
+    assert ei.value.code == ti._lib.TI_E_NAN
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_atom_without_incoming_edges_keeps_the_zeroing_path(precision):
+    """The accumulators are normally never zeroed: an atom's first row block REPLACES their contents (first-touch flag in the slot
+    table).  That needs every atom to receive messages; a graph with an atom nobody sends to falls back to explicit zeroing.  Both
+    must agree with the oracle, also on the second evaluation (stale accumulator contents) and in a multi-step rollout."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    A, F, L, B = 6, 64, 3, 70
+    src, dst, et = syn.fully_connected_template(A)
+    keep = dst != A - 1                                   # nobody sends to the last atom; it still sends to everyone
+    src, dst, et = src[keep], dst[keep], et[keep]
+    flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=3), W.painn_param_spec(0, F, L, 25))
+    eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision=precision)
+    orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+    x, cond = syn.molecule_coords(B, A, seed=1), syn.ambient_cond(B, A)
+    for t in (0.2, 0.7, 0.2):
+        assert rel_l2(eng.drift(x, t, cond), orc.drift(x, t, cond)) < DRIFT_TOL
+    grid = ti.engine.time_grid(0.0, 1.0, 4)
+    got, _ = eng.rollout(x, cond, grid, scheme="euler", save_every=0)
+    want, _ = orc.rollout(x, cond, grid, scheme="euler", save_every=0)
+    assert rel_l2(got - x, want - x) < 2e-5

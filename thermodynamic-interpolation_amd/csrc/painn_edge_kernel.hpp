@@ -27,6 +27,13 @@ struct EV {
 // accumulator element starts at zero and is only ever added to by the one wave that owns the molecule, in program
 // order (an atom's <= 31 incoming edges span at most three 16-row blocks of that wave).
 __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
+// accumulator update: a fire-and-forget atomic either way -- exchange on the first touch, add afterwards -- so that the later adds of the
+// same wave are ordered behind the replacement at L2 (a plain store takes another path)
+__device__ __forceinline__ void acc_out(float* p, float v, bool first)
+{
+    if (first) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else unsafeAtomicAdd(p, v);
+}
 
 // One wave = one molecule group, walked in blocks of 16 edge rows on the 16x16x4 MFMA (mfma_chain.hpp, namespace r16).
 // The waves of a workgroup share the weight-chunk stream (4 or 8 of them, see below); two waves per SIMD (F <= 128) hide each other's
@@ -172,10 +179,12 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
 #pragma unroll
         for (int r = 0; r < 4; ++r) qs.set_row(r, row_slot(mi[r]));
         int qnode;
+        bool qfirst;                                 // first block of that atom: replace the accumulator instead of adding (ti_internal.hpp)
         {
             const int sn = slotnode[blk * 16 + r16::QuarterSum<NS>::slot_of_quarter(q)];
-            const long long m2 = mg * p.G + (sn >> 8);
+            const long long m2 = mg * p.G + slot_mol(sn);
             qnode = (sn >= 0 && group_ok && m2 < p.B) ? (int)(m2 * p.A + (sn & 255)) : -1;
+            qfirst = (sn & SLOT_FIRST_TOUCH) != 0;
         }
 
         // (phi_c + b) * (w_c + b) for output chunk c (0 gates, 1 scale_edge_dir, 2 ds, 3 de, 4 cross gates), 32 features
@@ -197,10 +206,10 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
             if (NS == 2) {
                 const float z = qs.sum_pair(v0, v1);                 // quarter q: slot q & 1 of (q >> 1 ? v1 : v0)
-                if (qnode >= 0) add_noret(dst + (size_t)qnode * stride + 16 * (q >> 1), z);
+                if (qnode >= 0) acc_out(dst + (size_t)qnode * stride + 16 * (q >> 1), z, qfirst);
             } else {
                 const float z0 = qs.sum(v0), z1 = qs.sum(v1);        // quarter q: slot q
-                if (qnode >= 0) { float* d = dst + (size_t)qnode * stride; add_noret(d, z0); add_noret(d + 16, z1); }
+                if (qnode >= 0) { float* d = dst + (size_t)qnode * stride; acc_out(d, z0, qfirst); acc_out(d + 16, z1, qfirst); }
             }
         };
 

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
         int qnode;
         {
             const int sn = slotnode[blk * 16 + q];
-            const long long m2 = sn >> 8;
+            const long long m2 = slot_mol(sn);                              // (the first-touch flag of the word concerns the primal accumulators only)
             qnode = (sn >= 0 && group_ok && mg * p.G + m2 < p.B) ? (int)((vmg * p.G + m2) * p.A + (sn & 255)) : -1;     // TANGENT node
         }
         f32x4 dir[4], tdir[4], dd;

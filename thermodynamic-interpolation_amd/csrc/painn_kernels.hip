@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             for (int nb = 0; nb < NBK; ++nb) {
                 f32x4 vv[3], kk[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { vv[c] = r16::load_state<H16>(p.v, vo + c * F, nb, q); kk[c] = r16::load_block(cb + c * F, nb, q); }
+                for (int c = 0; c < 3; ++c) {
+                    vv[c] = p.first_layer ? f32x4{0, 0, 0, 0} : r16::load_state<H16>(p.v, vo + c * F, nb, q);
+                    kk[c] = p.first_layer ? f32x4{0, 0, 0, 0} : r16::load_block(cb + c * F, nb, q);
+                }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             snew.b[nb] = so;
             if (ok) {
                 r16::store_state<H16>(p.s, so_, nb, q, so);
-                r16::store_block(ab, nb, q, f32x4{0, 0, 0, 0});
+                if (p.zero_acc) r16::store_block(ab, nb, q, f32x4{0, 0, 0, 0});
             }
         }
     }
@@ -210,10 +213,12 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_update_kernel(c
             if (ok) {
                 r16::store_state<H16>(p.v, vo + c * F, 2 * ch, q, t.b[2 * ch] + a0 * gg.b[2 * ch]);
                 r16::store_state<H16>(p.v, vo + c * F, 2 * ch + 1, q, t.b[2 * ch + 1] + a1 * gg.b[2 * ch + 1]);
-                r16::store_block(db + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
-                r16::store_block(db + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
-                r16::store_block(cb + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
-                r16::store_block(cb + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
+                if (p.zero_acc) {
+                    r16::store_block(db + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
+                    r16::store_block(db + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
+                    r16::store_block(cb + c * F, 2 * ch, q, f32x4{0, 0, 0, 0});
+                    r16::store_block(cb + c * F, 2 * ch + 1, q, f32x4{0, 0, 0, 0});
+                }
             }
             pipe.release();
         }

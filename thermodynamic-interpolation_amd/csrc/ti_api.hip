@@ -131,6 +131,9 @@ struct ti_handle {
         int max_slots = 0;                        // most destination atoms in any row block (<= EDGE_MAX_SLOTS)
     } tpl[2];
     int n_tpl = 1, active = 0, parts = 1, max_slots = 0, pinned_tpl = TI_TEMPLATE_AUTO;
+    // every atom has incoming edges: the edge kernels' first touch of an accumulator replaces its contents (ti_internal.hpp
+    // SLOT_FIRST_TOUCH) and nothing zeroes the accumulators between layers or calls; otherwise the update kernel zeroes them as before
+    bool first_touch = false;
     struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
     DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
@@ -212,12 +215,17 @@ static int fill_part(const ti_handle* h, const int32_t* src, const int32_t* dst,
     const int per = k1 - k0;
     for (int i = 0; i < nblk * RB; ++i) { rw[i] = (uint32_t)63 << 18; sn[i] = -1; }
     std::vector<int> nslot(std::max(nblk, 1), 0), last_key(std::max(nblk, 1), -1);
+    std::vector<char> touched((size_t)count * 256, 0);          // rows are visited in increasing order: the first block seen is the first executed
     int most = 0;
     for (int m = 0; m < count; ++m)
         for (int kk = 0; kk < per; ++kk) {
             const int r = pos[(size_t)m * per + kk], blk = r / RB, k = h->perm[k0 + kk];
             const int key = m * 256 + dst[k];
-            if (key != last_key[blk]) { sn[(size_t)blk * RB + nslot[blk]] = (m << 8) | dst[k]; ++nslot[blk]; last_key[blk] = key; }
+            if (key != last_key[blk]) {
+                const int32_t first = (h->first_touch && !touched[key]) ? ti::SLOT_FIRST_TOUCH : 0;
+                touched[key] = 1;
+                sn[(size_t)blk * RB + nslot[blk]] = first | (m << 8) | dst[k]; ++nslot[blk]; last_key[blk] = key;
+            }
             most = std::max(most, nslot[blk]);
             rw[r] = 1u | ((uint32_t)m << 1) | ((uint32_t)src[k] << 6) | ((uint32_t)dst[k] << 11) | ((uint32_t)etype[k] << 16) |
                     ((uint32_t)(nslot[blk] - 1) << 18);
@@ -229,6 +237,11 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
 {
     const int A = h->d.n_atoms, E = h->d.n_edges;
     constexpr int RB = ti::EDGE_ROWS_PER_BLOCK;
+    {
+        std::vector<char> has_in(A, 0);
+        for (int k = 0; k < E; ++k) has_in[dst[k]] = 1;
+        h->first_touch = E > 0 && std::all_of(has_in.begin(), has_in.end(), [](char c) { return c != 0; });
+    }
     h->perm.resize(E);
     for (int k = 0; k < E; ++k) h->perm[k] = k;
     std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) {
@@ -542,10 +555,18 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
         HIP_CHECK(hipMemsetAsync(h->tcacc.p, 0, 3 * nb, st));
     }
     const size_t vbytes = (size_t)N * 3 * F * sizeof(float);
-    HIP_CHECK(hipMemsetAsync(h->v.p, 0, prec == TI_PREC_F16 ? vbytes / 2 : vbytes, st));
-    HIP_CHECK(hipMemsetAsync(h->dvacc.p, 0, vbytes, st));
-    HIP_CHECK(hipMemsetAsync(h->cacc.p, 0, vbytes, st));
-    HIP_CHECK(hipMemsetAsync(h->dsacc.p, 0, (size_t)N * F * sizeof(float), st));
+    // With first-touch accumulators (every atom has incoming edges) nothing needs zeroing: layer 0's edge kernel replaces dsacc and
+    // dvacc, its update kernel does not read v and cacc (zero by definition), every later layer replaces all three.  The forward-mode
+    // passes read the primal v and cacc of layer 0 themselves, and with no layers the readout reads v: then they are cleared.
+    const bool ft = h->first_touch && h->tap < 0;      // (the debug taps read "state + pending accumulators": they want them zeroed after use)
+    if (!ft || jr || L == 0) {
+        HIP_CHECK(hipMemsetAsync(h->v.p, 0, prec == TI_PREC_F16 ? vbytes / 2 : vbytes, st));
+        HIP_CHECK(hipMemsetAsync(h->cacc.p, 0, vbytes, st));
+    }
+    if (!ft) {
+        HIP_CHECK(hipMemsetAsync(h->dvacc.p, 0, vbytes, st));
+        HIP_CHECK(hipMemsetAsync(h->dsacc.p, 0, (size_t)N * F * sizeof(float), st));
+    }
     {
         EmbedParams p{};
         p.stream = h->S(h->st_embed16); p.nch = h->st_embed16.nch; p.mlp = h->vec(h->embed);
@@ -611,6 +632,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             UpdateParams p{};
             p.stream = h->S(h->st_update[l]); p.nch = h->st_update[l].nch; p.vecs = h->upd_vecs.p + (size_t)l * 10 * F;
             p.N = N; p.s = h->s.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.P = h->P.p;
+            p.first_layer = l == 0; p.zero_acc = !ft;
             Timed tm(h, TI_KERNEL_PAINN_UPDATE);
             HIP_CHECK(launch_update(NB, l + 1 < L, prec, p, st));
         }

@@ -16,6 +16,11 @@ namespace ti {
 // rows, one wave walks G*E_m rows) and "latency" (G = 1, the destination atoms of a molecule cut into P parts, each part padded
 // to whole row blocks and walked by its own wave: P times the waves for small batches).  A kernel's group index counts
 // (molecule group, part):  gi = mg * parts + part;  rows / slotnode hold [parts][nblk*16] entries.
+// slotnode word: -1 = no such slot, else  atom | molecule-in-group << 8 | SLOT_FIRST_TOUCH: this block is the first one (in the owning
+// wave's program order) that holds rows of the atom -- its sums REPLACE the accumulator contents instead of adding to them, so nobody
+// has to zero the accumulators between layers.  Set only when every atom of the graph has incoming edges (ti_api.hip).
+constexpr int32_t SLOT_FIRST_TOUCH = 1 << 30;
+__host__ __device__ inline int slot_mol(int32_t sn) { return (sn >> 8) & 0x3fffff; }
 // The E_m edges of one molecule are sorted by (dst, src); G molecules form a "group" whose G*E_m edge rows are padded
 // to NBLK blocks of EDGE_ROWS_PER_BLOCK rows.  One wave owns one group, so every per-atom sum over incoming edges stays inside a wave
 // in that wave's program order (deterministic).  Within a block, the distinct (molecule, dst atom) pairs are numbered as "slots";
@@ -68,6 +73,8 @@ struct UpdateParams {
     const float* vecs;                      // [10][F] (painn_kernels.hip: struct UV)
     long long N;
     float *s, *v, *dsacc, *dvacc, *cacc, *P;
+    int first_layer;                        // v and cacc are zero by definition (nothing has written them yet): not read
+    int zero_acc;                           // reset the accumulators after use (0 when the edge kernels overwrite on first touch)
 };
 
 struct ReadoutParams {
