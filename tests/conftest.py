@@ -9,6 +9,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The CPU oracle is OpenMP code.  A GPU box reports all of its host's cores (128+) but a one-GPU job owns a share of ~16: with the
+# default team size every parallel region is oversubscribed 8x and, when the neighbours are busy, spin-waiting barriers turn a
+# 1-second check into a minute (seen in round 2: a 70-second suite stalled for minutes).  Tests need the oracle's answers, not its
+# speed: a team that fits the share, and sleeping waits.  (bench.py's cpu_baseline leg sets its own thread count.)
+def _cpu_share():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_share()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

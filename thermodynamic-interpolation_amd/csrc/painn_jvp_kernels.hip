@@ -48,6 +48,12 @@ struct RV {          // readout vector block: b0 g0 be0 b1 g1 be1 w2_gate Vr
 };
 
 __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
+// accumulator update with the first-touch rule of the primal edge kernel (ti_internal.hpp SLOT_FIRST_TOUCH)
+__device__ __forceinline__ void acc_out(float* p, float v, bool first)
+{
+    if (first) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else unsafeAtomicAdd(p, v);
+}
 
 #define Z4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
@@ -327,10 +333,12 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
 #pragma unroll
         for (int r = 0; r < 4; ++r) qs.set_row(r, row_slot(mi[r]));
         int qnode;
+        bool qfirst;                                 // first block of that atom: its sums replace the tangent accumulators' contents
         {
             const int sn = slotnode[blk * 16 + q];
-            const long long m2 = slot_mol(sn);                              // (the first-touch flag of the word concerns the primal accumulators only)
+            const long long m2 = slot_mol(sn);
             qnode = (sn >= 0 && group_ok && mg * p.G + m2 < p.B) ? (int)((vmg * p.G + m2) * p.A + (sn & 255)) : -1;     // TANGENT node
+            qfirst = (sn & SLOT_FIRST_TOUCH) != 0;
         }
         f32x4 dir[4], tdir[4], dd;
 #pragma unroll
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
         };
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
             const float z0 = qs.sum(v0), z1 = qs.sum(v1);
-            if (qnode >= 0) { float* d = dst + (size_t)qnode * stride; add_noret(d, z0); add_noret(d + 16, z1); }
+            if (qnode >= 0) { float* d = dst + (size_t)qnode * stride; acc_out(d, z0, qfirst); acc_out(d + 16, z1, qfirst); }
         };
 
 #pragma unroll 1
@@ -644,37 +652,45 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kern
     auto stat = [&](int which, int nb) { return nsp[(size_t)(which * NBK + nb) * 64]; };
 
     // ---- phase A: tv_eff (parked in tdvacc), n' = sum_c (vv_c / |vv|) . (V tv_eff_c)
+    // Feature block outermost, like the primal update kernel: tv, tcacc and tdvacc are read once each (the cross product needs all three
+    // components of a block; per-component loops read tv three times and tcacc twice, and those repeats came from HBM).
     A16 tn;
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) tn.b[nb] = Z4;
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-        OP tve;
-        {
-            A16 u;
+    {
+        A16 u[3];
 #pragma unroll
-            for (int nb = 0; nb < NBK; ++nb) {
-                const f32x4 v1 = r16::load_block(vb + c1 * F, nb, q), v2 = r16::load_block(vb + c2 * F, nb, q);
-                const f32x4 k1 = r16::load_block(cb + c1 * F, nb, q), k2 = r16::load_block(cb + c2 * F, nb, q);
-                const f32x4 tvc = r16::load_block(tvb + c * F, nb, q), tdd = r16::load_block(tdb + c * F, nb, q);
-                const f32x4 tv1 = r16::load_block(tvb + c1 * F, nb, q), tv2 = r16::load_block(tvb + c2 * F, nb, q);
-                const f32x4 tk1 = r16::load_block(tcb + c1 * F, nb, q), tk2 = r16::load_block(tcb + c2 * F, nb, q);
-                u.b[nb] = (tvc + tdd) + ((tk1 * v2 + k1 * tv2) - (tk2 * v1 + k2 * tv1));
-                if (ok) r16::store_block(tdb + c * F, nb, q, u.b[nb]);      // of the accumulators only tdvacc[c] fed this component
+        for (int nb = 0; nb < NBK; ++nb) {
+            f32x4 vv[3], kk[3], tvv[3], tkk[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                vv[c] = r16::load_block(vb + c * F, nb, q); kk[c] = r16::load_block(cb + c * F, nb, q);
+                tvv[c] = r16::load_block(tvb + c * F, nb, q); tkk[c] = r16::load_block(tcb + c * F, nb, q);
             }
-            tve.set(u);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                const f32x4 tdd = r16::load_block(tdb + c * F, nb, q);
+                u[c].b[nb] = (tvv[c] + tdd) + ((tkk[c1] * vv[c2] + kk[c1] * tvv[c2]) - (tkk[c2] * vv[c1] + kk[c2] * tvv[c1]));
+                if (ok) r16::store_block(tdb + c * F, nb, q, u[c].b[nb]);
+            }
         }
 #pragma unroll
-        for (int ch = 0; ch < NB; ++ch) {
-            const f32x4* wl = pipe.acquire();
-            f32x4 b0 = Z4, b1 = Z4;
-            r16::gemm_bt(b0, b1, tve, wl, lane);
-            tn.b[2 * ch] += stat(c, 2 * ch) * b0; tn.b[2 * ch + 1] += stat(c, 2 * ch + 1) * b1;
-            pipe.release();
+        for (int c = 0; c < 3; ++c) {
+            OP tve;
+            tve.set(u[c]);
+#pragma unroll
+            for (int ch = 0; ch < NB; ++ch) {
+                const f32x4* wl = pipe.acquire();
+                f32x4 b0 = Z4, b1 = Z4;
+                r16::gemm_bt(b0, b1, tve, wl, lane);
+                tn.b[2 * ch] += stat(c, 2 * ch) * b0; tn.b[2 * ch + 1] += stat(c, 2 * ch + 1) * b1;
+                pipe.release();
+            }
         }
     }
     // ---- phase B: tangent of MLP([ |vv| , s + ds ])
+    A16 tsn;                                        // ts + tds, then ts after the update (phase D's operand): read once, kept in registers
     OP th2;
     {
         A16 u;
@@ -692,12 +708,9 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kern
         }
         {
             OP tss;
-            {
-                A16 y;
 #pragma unroll
-                for (int nb = 0; nb < NBK; ++nb) y.b[nb] = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
-                tss.set(y);
-            }
+            for (int nb = 0; nb < NBK; ++nb) tsn.b[nb] = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
+            tss.set(tsn);
 #pragma unroll
             for (int ch = 0; ch < NB; ++ch) {
                 const f32x4* wl = pipe.acquire();
@@ -745,16 +758,17 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kern
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int nb = 2 * ch + k;
-            f32x4 so = r16::load_block(tsb, nb, q) + r16::load_block(tab, nb, q);
+            f32x4 so = tsn.b[nb];
             const f32x4 tqq = k ? tq1 : tq0, taa = k ? ta1 : ta0, nrm = stat(3, nb), qq = stat(8, nb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float n = nrm[r], dn = tn.b[nb][r];
                 so[r] = so[r] + (((2.0f * n) * dn) * qq[r] + (n * n) * tqq[r] + taa[r]);
             }
+            tsn.b[nb] = so;
             if (ok) {
                 r16::store_block(tsb, nb, q, so);
-                r16::store_block(tab, nb, q, Z4);
+                if (p.zero_acc) r16::store_block(tab, nb, q, Z4);
             }
         }
     }
@@ -771,27 +785,26 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kern
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         OP tve;
-        {
-            A16 u;
-            r16::load_set(u, tdb + c * F, q);
-            tve.set(u);
-        }
+        A16 u;                                      // the parked tv_eff row: operand and addend, read once
+        r16::load_set(u, tdb + c * F, q);
+        tve.set(u);
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();
             f32x4 b0 = Z4, b1 = Z4;
             r16::gemm_bt(b0, b1, tve, wl, lane);
             pipe.release();
-            const f32x4 e0 = r16::load_block(tdb + c * F, 2 * ch, q), e1 = r16::load_block(tdb + c * F, 2 * ch + 1, q);
             if (ok) {
-                r16::store_block(tvb + c * F, 2 * ch, q, e0 + (b0 * stat(9, 2 * ch) + stat(10 + c, 2 * ch) * tgg.b[2 * ch]));
-                r16::store_block(tvb + c * F, 2 * ch + 1, q, e1 + (b1 * stat(9, 2 * ch + 1) + stat(10 + c, 2 * ch + 1) * tgg.b[2 * ch + 1]));
-                r16::store_block(tdb + c * F, 2 * ch, q, Z4);
-                r16::store_block(tdb + c * F, 2 * ch + 1, q, Z4);
+                r16::store_block(tvb + c * F, 2 * ch, q, u.b[2 * ch] + (b0 * stat(9, 2 * ch) + stat(10 + c, 2 * ch) * tgg.b[2 * ch]));
+                r16::store_block(tvb + c * F, 2 * ch + 1, q, u.b[2 * ch + 1] + (b1 * stat(9, 2 * ch + 1) + stat(10 + c, 2 * ch + 1) * tgg.b[2 * ch + 1]));
+                if (p.zero_acc) {
+                    r16::store_block(tdb + c * F, 2 * ch, q, Z4);
+                    r16::store_block(tdb + c * F, 2 * ch + 1, q, Z4);
+                }
             }
         }
     }
-    if (ok) {
+    if (ok && p.zero_acc) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -800,11 +813,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_update_kern
     // ---- phase D: tangent of P for the next message block (no bias)
     if (p.has_next) {
         OP sn;
-        {
-            A16 t;
-            r16::load_set(t, tsb, q);
-            sn.set(t);
-        }
+        sn.set(tsn);                                // the rows written above, still in registers
 #pragma unroll
         for (int ch = 0; ch < NB; ++ch) {
             const f32x4* wl = pipe.acquire();

@@ -625,6 +625,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             p.N = VN; p.B = B; p.A = A; p.D = jr->D; p.G = h->G; p.has_next = l + 1 < L;
             p.v = h->v.p; p.cacc = h->cacc.p; p.ns = reinterpret_cast<const float4*>(h->nodest.p);
             p.ts = h->ts.p; p.tv = h->tv.p; p.tdsacc = h->tdsacc.p; p.tdvacc = h->tdvacc.p; p.tcacc = h->tcacc.p; p.tP = h->tP.p;
+            p.zero_acc = !ft;
             Timed tm(h, TI_KERNEL_PAINN_JVP_UPDATE);
             HIP_CHECK(launch_jvp_update(NB, split, p, st));
         }

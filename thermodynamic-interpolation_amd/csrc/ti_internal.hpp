@@ -128,6 +128,7 @@ struct JvpUpdateParams {
     const float *v, *cacc;                  // primal, as the primal edge kernel left them
     const float4* ns;                       // primal node pass output of this layer
     float *ts, *tv, *tdsacc, *tdvacc, *tcacc, *tP;
+    int zero_acc;                           // reset the tangent accumulators after use (0 with first-touch slot tables)
 };
 struct JvpReadoutParams {
     const float4* stream; int nch; const float* vecs; float b2_gate;      // vecs: b0 g0 be0 b1 g1 be1 w2_gate Vr (x F)
