@@ -60,7 +60,7 @@ def child(batch, steps, precision, small):
     F, L, A = 128, 5, 18
     tpl = syn.fully_connected_template(A)
     flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 0), W.painn_param_spec(W.AMBIENT, F, L, 25))
-    os.environ["TI_TEMPLATE"] = "throughput"
+    os.environ["TI_TEMPLATE"] = os.environ.get("TI_VB_TEMPLATE", "throughput")
     eng = E.PainnEngine(W.AMBIENT, F, L, A, *tpl, np.arange(A), flat, temp_length=100.0, precision=precision)
     xs, cs = syn.molecule_coords(64, A, seed=7), syn.ambient_cond(64, A)
     d = eng.drift(xs, 0.3, cs)
