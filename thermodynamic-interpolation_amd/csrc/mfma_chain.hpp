@@ -771,6 +771,34 @@ __device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const OpndH<NB
 template <int NBK>
 __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const OpndH<NBK>& in, const f32x4* wl4, int lane) { gemm_half_chunk<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
 
+// product of the pipe's current chunk with operand set `in` (FLIP: features on lanes).  The caller releases the chunk.
+template <bool FLIP, class OP, class PIPE>
+__device__ __forceinline__ void gemm_on_pipe(f32x4& acc0, f32x4& acc1, const OP& in, PIPE& pipe, int lane)
+{
+    const f32x4* wl = pipe.acquire();
+    if constexpr (FLIP) gemm_fl(acc0, acc1, in, wl, lane);
+    else gemm_bt(acc0, acc1, in, wl, lane);
+}
+// An operand set as the 16-byte registers it is made of, parked in / fetched from HBM in register order ([register][lane]: every
+// instruction moves 1 KB contiguous).  dst / src already point at this lane's slot.
+template <typename OP>
+__device__ __forceinline__ void opnd_store(const OP& o, f32x4* dst)
+{
+    constexpr int N = sizeof(OP) / 16;
+    f32x4 r[N];
+    __builtin_memcpy(r, &o, sizeof(OP));
+#pragma unroll
+    for (int k = 0; k < N; ++k) dst[k * 64] = r[k];
+}
+template <typename OP>
+__device__ __forceinline__ void opnd_load(OP& o, const f32x4* src)
+{
+    constexpr int N = sizeof(OP) / 16;
+    f32x4 r[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = src[k * 64];
+    __builtin_memcpy(&o, r, sizeof(OP));
+}
 // operand type of a matrix path: PREC 0 = f32 MFMA, 1 = split fp16 (hi + 2^-11 lo, 3 products), 2 = fp16 storage mode (1 product)
 template <int NBK, int PREC> struct OpSel { using type = Opnd<NBK, PREC == 1>; };
 template <int NBK> struct OpSel<NBK, 2> { using type = OpndH<NBK>; };

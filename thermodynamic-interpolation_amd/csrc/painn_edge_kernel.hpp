@@ -83,46 +83,50 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
         mol = mol < p.B ? mol : p.B - 1;
         const long long nsrc = mol * p.A + row_src(meta), ndst = mol * p.A + row_dst(meta);
         const size_t erow0 = ((size_t)gi * p.nblk + blk) * 16;
-        float dist;
-        {
+        // The geometry and its encoding do not change between the layers of one drift evaluation: layer 0 computes them and parks, per
+        // row, edge_dir (16 B) and the encoding AS THE MATRIX OPERAND it is used as (the register image of `enc`, F * 4 bytes, F * 2 in the
+        // fp16 mode); the later layers load both -- no x gather behind the row word, no sqrt / divisions, no 16 sincos per lane, no
+        // hi/lo conversion of the encoding.
+        OP enc;
+        f32x4* const enc_park = reinterpret_cast<f32x4*>(p.enc) + (erow0 / 16) * (sizeof(OP) / 16) * 64 + lane;
+        f32x4* const geo_park = reinterpret_cast<f32x4*>(p.geo) + erow0 + j;
+        if constexpr (FIRST) {
             const float rx = p.x[nsrc * 3 + 0] - p.x[ndst * 3 + 0];
             const float ry = p.x[nsrc * 3 + 1] - p.x[ndst * 3 + 1];
             const float rz = p.x[nsrc * 3 + 2] - p.x[ndst * 3 + 2];
-            dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
             const float den = 1.0f + dist;                       // edge_dir = r / (1 + d)   (not a unit vector)
             if (q == 0) {
                 f32x4 dd = {rx / den, ry / den, rz / den, 0.f};
                 *reinterpret_cast<f32x4*>(scratch + j * 4) = dd;
+                if (group_ok) *geo_park = dd;
             }
+            A16 t;
+            r16::posenc_set(t, dist / p.length_scale, q);
+            enc.set(t);
+            if (group_ok) r16::opnd_store(enc, enc_park);
+        } else {
+            if (q == 0) *reinterpret_cast<f32x4*>(scratch + j * 4) = *geo_park;
+            r16::opnd_load(enc, enc_park);
         }
         // ---- w(enc(d)) hidden layers
         OP g2;
         {
             OP g1;
             A16 t1;
-            {
-                OP enc;
-                {
-                    A16 t;
-                    r16::posenc_set(t, dist / p.length_scale, q);
-                    enc.set(t);
-                }
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    const f32x4* wl = pipe.acquire();
-                    f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
-                    r16::gemm_bt(a0, a1, enc, wl, lane);
-                    t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
-                    pipe.release();
-                }
+            for (int c = 0; c < NB; ++c) {
+                f32x4 a0 = r16::load_block(vec + EV::W_B0 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B0 * F, 2 * c + 1, q);
+                r16::gemm_on_pipe<false>(a0, a1, enc, pipe, lane);
+                t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
+                pipe.release();
             }
             r16::ln_silu(t1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
             g1.set(t1);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
-                r16::gemm_bt(a0, a1, g1, wl, lane);
+                r16::gemm_on_pipe<false>(a0, a1, g1, pipe, lane);
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
@@ -146,10 +150,9 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
             const float e_inv = r16::pow2_inverse(e_scale);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                const f32x4* wl = pipe.acquire();
                 // P[src] (the s[src] half of the Linear) / 2^k + W e' of the scaled rows, then * 2^k: all exact scalings
                 f32x4 a0 = r16::load_state<H16>(p.P, (size_t)nsrc * F, 2 * c, q) * e_inv, a1 = r16::load_state<H16>(p.P, (size_t)nsrc * F, 2 * c + 1, q) * e_inv;
-                r16::gemm_bt(a0, a1, ein, wl, lane);
+                r16::gemm_on_pipe<false>(a0, a1, ein, pipe, lane);
                 a0 *= e_scale; a1 *= e_scale;
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
@@ -158,9 +161,8 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
             h1.set(t1);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                const f32x4* wl = pipe.acquire();
                 f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
-                r16::gemm_bt(a0, a1, h1, wl, lane);
+                r16::gemm_on_pipe<false>(a0, a1, h1, pipe, lane);
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
@@ -191,11 +193,9 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
         // fo .. fo+31 as two 16-feature blocks
         auto out_pair = [&](int c, int nbo, f32x4& r0, f32x4& r1) {
             f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-            const f32x4* wl0 = pipe.acquire();
-            r16::gemm_fl(a0, a1, h2, wl0, lane);
+            r16::gemm_on_pipe<true>(a0, a1, h2, pipe, lane);
             pipe.release();
-            const f32x4* wl1 = pipe.acquire();
-            r16::gemm_fl(b0, b1, g2, wl1, lane);
+            r16::gemm_on_pipe<true>(b0, b1, g2, pipe, lane);
             pipe.release();
             const float* bp = vec + (EV::P_B2 + c) * F + 32 * nbo + j;
             const float* bw = vec + (EV::W_B2 + c) * F + 32 * nbo + j;
@@ -227,11 +227,9 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                 // so e += de is two 8-byte stores per lane -- no atomics, no second read of e
                 f32x4 a0 = r16::load_block(vec + (EV::P_B2 + 3) * F, 2 * nbo, q), a1 = r16::load_block(vec + (EV::P_B2 + 3) * F, 2 * nbo + 1, q);
                 f32x4 b0 = r16::load_block(vec + (EV::W_B2 + 3) * F, 2 * nbo, q), b1 = r16::load_block(vec + (EV::W_B2 + 3) * F, 2 * nbo + 1, q);
-                const f32x4* wl0 = pipe.acquire();
-                r16::gemm_bt(a0, a1, h2, wl0, lane);
+                r16::gemm_on_pipe<false>(a0, a1, h2, pipe, lane);
                 pipe.release();
-                const f32x4* wl1 = pipe.acquire();
-                r16::gemm_bt(b0, b1, g2, wl1, lane);
+                r16::gemm_on_pipe<false>(b0, b1, g2, pipe, lane);
                 pipe.release();
                 r16::h4 n0, n1;
                 // runtime nbo: select the k-step of ein without dynamic register indexing

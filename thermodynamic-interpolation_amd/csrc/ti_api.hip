@@ -137,7 +137,7 @@ struct ti_handle {
     struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
     DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
-    DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, b1, b2, xt, edge_vecs, upd_vecs;
+    DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, enc, geo, b1, b2, xt, edge_vecs, upd_vecs;
     int tap = -1; long long last_B = 0;
     // forward-mode derivative (painn_jvp_kernels.hip): tangent twins over virtual molecules, sized on first use
     std::vector<Stream> st_jvp_update, st_jvp_phi; Stream st_jvp_readout{}; std::vector<int> jvp_phi_pad;
@@ -480,6 +480,8 @@ void ensure_painn_ws(ti_handle* h, long long B)
     h->s.alloc((N * F + se - 1) / se); h->P.alloc((N * F + se - 1) / se);
     h->v.alloc((N * 3 * F + se - 1) / se); h->dvacc.alloc(N * 3 * F); h->cacc.alloc(N * 3 * F); h->dsacc.alloc(N * F);
     h->e.alloc((edge_rows_for(h, B) * F + se - 1) / se);
+    // parked geometry of a drift evaluation (painn_edge_kernel.hpp): the encoding operand of every edge row (as many bytes as e) and edge_dir
+    h->enc.alloc((edge_rows_for(h, B) * F + se - 1) / se); h->geo.alloc(edge_rows_for(h, B) * 4);
     h->divb.alloc(B); h->div2.alloc(B); h->dl.alloc(B); h->dlscaled.alloc(B);
     h->cap = B;
 }
@@ -606,7 +608,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             p.stream = h->S(h->st_edge[l]); p.nch = h->st_edge[l].nch; p.vecs = h->edge_vecs.p + (size_t)l * 21 * F;
             p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p; p.nslots = nullptr;
             p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.max_slots = h->max_slots; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
-            p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p;
+            p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p; p.enc = h->enc.p; p.geo = h->geo.p;
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
             HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
         }

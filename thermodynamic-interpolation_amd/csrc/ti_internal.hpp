@@ -57,6 +57,8 @@ struct EdgeParams {
     float* dvacc;                           // [B*A][3][F] += sum (sed*dir + gates*v[src])
     float* cacc;                            // [B*A][3][F] += sum cg*dir   (crossed with v[dst] in the update kernel)
     float* e;                               // [n_groups*nblk*16][F]
+    float* enc;                             // [n_groups*nblk][operand registers][64] parked encoding operand of every row block (layer 0 writes, the others read)
+    float* geo;                             // [n_groups*nblk*16][4] parked edge_dir
 };
 
 struct EmbedParams {
