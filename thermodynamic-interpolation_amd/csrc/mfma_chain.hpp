@@ -51,6 +51,13 @@ __device__ __forceinline__ void lane_swap16(float& a, float& b) { asm("s_nop 1\n
 __device__ __forceinline__ void lane_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 
 // v + (the value of the lane 32 away), in every lane
+// 1 / sqrt(x) for the LayerNorm scale: v_rsq_f32 (1 ulp) and one Newton step -- 5 instructions, within an ulp of the correctly rounded
+// quotient; `1.0f / sqrtf(x)` compiles to ~25 (IEEE square root + IEEE division fix-ups) once per row and LayerNorm.
+__device__ __forceinline__ float rsqrt_nr(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    return r * __builtin_fmaf(-0.5f * x * r, r, 1.5f);
+}
 __device__ __forceinline__ float xhalf_sum(float v)
 {
     float a = v, b = v;
@@ -295,7 +302,7 @@ __device__ __forceinline__ void ln_silu(Act<NB>& a, const float* __restrict__ ga
             var = fmaf(d, d, var);
         }
     var = xhalf_sum(var);
-    const float rstd = 1.0f / sqrtf(var * invF + 1e-5f);
+    const float rstd = rsqrt_nr(var * invF + 1e-5f);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const f32x16 gm = load_block(gamma, nb, h);
@@ -444,7 +451,7 @@ __device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const f
             const float d = a.b[nb][r] - mean;
             var = fmaf(d, d, var);
         }
-    const float rstd = 1.0f / sqrtf(xquarters(var) * invF + 1e-5f);
+    const float rstd = rsqrt_nr(xquarters(var) * invF + 1e-5f);
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
         const f32x4 gm = load_block(gamma, nb, q), bt = load_block(beta, nb, q);
@@ -490,7 +497,7 @@ __device__ __forceinline__ void ln_silu_dual(Act<NBK>& a, Act<NBK>& da, const fl
             const float d = a.b[nb][r] - mean;
             var = fmaf(d, d, var);
         }
-    const float rstd = 1.0f / sqrtf(xquarters(var) * invF + 1e-5f);
+    const float rstd = rsqrt_nr(xquarters(var) * invF + 1e-5f);
     float pr = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb)
@@ -530,7 +537,7 @@ __device__ __forceinline__ void ln_silu_stats(Act<NBK>& a, Act<NBK>& n_out, Act<
             const float d = a.b[nb][r] - mean;
             var = fmaf(d, d, var);
         }
-    const float rstd = 1.0f / sqrtf(xquarters(var) * invF + 1e-5f);
+    const float rstd = rsqrt_nr(xquarters(var) * invF + 1e-5f);
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
         const f32x4 gm = load_block(gamma, nb, q), bt = load_block(beta, nb, q);
@@ -611,6 +618,51 @@ __device__ __forceinline__ float xquarters_max(float v)
     return fmaxf(a, b);
 }
 
+// The split of four values in 8 vector instructions: hi = fp16(v) is one v_cvt_pk_f16_f32 per pair, and each scaled residual
+// fp16(2^11 (v - hi)) = fp16(fma(f32(hi), -2^11, 2^11 v)) is ONE v_fma_mix{lo,hi}_f16 that reads its half of the packed hi pair as it
+// is and writes its half of the packed lo pair.  2^11 v and 2^11 hi are exact and v - hi is exactly representable, so the value that
+// is rounded to fp16 is the one of "convert hi back, subtract, scale, pack" (12 instructions per four values) -- the same bits,
+// fp16 subnormals included (tools/micro/split_probe.hip compares the two forms on 2^20 values).  hipcc forms the mix instructions
+// for one pair in four and SLP-packs the rest into cvt / v_pk_fma_f32 / cvt_pk sequences, hence the inline asm.
+// Hazard: v_fma_mixlo / mixhi write HALF a register; on gfx940/950 a vector instruction that reads such a register needs a wait
+// state behind the write (hipcc inserts it for its own instructions, not inside inline asm).  A first version with mixlo / mixhi of
+// one pair back to back lost low halves now and then (tangent taps off by 4e-5; the probe, with other instructions in between, saw
+// nothing).  Here two pairs are interleaved and the block begins and ends with s_nop: at least two issue slots between every half
+// write and the next read of that register, one in front of the first read of the packed hi pairs.  With it the tangent taps meet
+// their 1e-5 bar with this form in every kernel (tests/test_gpu_divergence.py).  -DTI_SPLIT_REFERENCE=1 builds the 12-instruction
+// form; its drift differs from this one's by 2.5e-7 (|b| ~ 0.1) although the probe finds the same bits for the same input: under
+// hipcc's default -ffp-contract=fast the reference form's `v - hi` fuses with the multiplication that produced v (SiLU's y * rcp),
+// i.e. it splits the unrounded product, while this form splits the rounded fp32 value it is given.
+#ifndef TI_SPLIT_REFERENCE
+#define TI_SPLIT_REFERENCE 0
+#endif
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_quad(const f32x4& v, h4s& hi, h4s& lo)
+{
+    hi = h4s{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    if constexpr (TI_SPLIT_REFERENCE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lo[i] = (_Float16)((v[i] - (float)hi[i]) * 2048.0f);
+    } else {
+        const unsigned ha = __builtin_bit_cast(unsigned, h2{hi[0], hi[1]}), hb = __builtin_bit_cast(unsigned, h2{hi[2], hi[3]});
+        const f32x4 s = v * 2048.0f;
+        const float c = -2048.0f;
+        unsigned da, db;
+        asm("s_nop 0\n\t"
+            "v_fma_mixlo_f16 %0, %2, %4, %5 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %1, %3, %4, %7 op_sel_hi:[1,0,0]\n\t"
+            "s_nop 0\n\t"
+            "v_fma_mixhi_f16 %0, %2, %4, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %1, %3, %4, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "s_nop 1"
+            : "=&v"(da), "=&v"(db)
+            : "v"(ha), "v"(hb), "s"(c), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
+        const h2 la = __builtin_bit_cast(h2, da), lb = __builtin_bit_cast(h2, db);
+        lo = h4s{la[0], la[1], lb[0], lb[1]};
+    }
+}
+
 template <int NBK, bool SPLIT>
 struct Opnd {                                   // fp32 operand: the activation set itself
     Act<NBK> a;
@@ -626,11 +678,11 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
 #pragma unroll
         for (int m = 0; m < NBK / 2; ++m)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v = i < 4 ? x.b[2 * m][i] : x.b[2 * m + 1][i - 4];
-                const _Float16 h = (_Float16)v;
-                hi[m][i] = h;
-                lo[m][i] = (_Float16)((v - (float)h) * 2048.0f);
+            for (int i = 0; i < 8; i += 4) {
+                h4s h, l;
+                split_quad(i < 4 ? x.b[2 * m] : x.b[2 * m + 1], h, l);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { hi[m][i + r] = h[r]; lo[m][i + r] = l[r]; }
             }
     }
     // For operand sets that are NOT the output of a LayerNorm (the residual streams e, s, v, |Vv|: any magnitude fp32 holds):
@@ -655,11 +707,11 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
 #pragma unroll
         for (int m2 = 0; m2 < NBK / 2; ++m2)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v = (i < 4 ? x.b[2 * m2][i] : x.b[2 * m2 + 1][i - 4]) * inv;
-                const _Float16 h = (_Float16)v;
-                hi[m2][i] = h;
-                lo[m2][i] = (_Float16)((v - (float)h) * 2048.0f);
+            for (int i = 0; i < 8; i += 4) {
+                h4s h, l;
+                split_quad((i < 4 ? x.b[2 * m2] : x.b[2 * m2 + 1]) * inv, h, l);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { hi[m2][i + r] = h[r]; lo[m2][i + r] = l[r]; }
             }
         return scale;
     }
