@@ -204,7 +204,8 @@ int ti_profile_read(ti_handle* h, int kernel, int64_t* n_launches, double* total
  * 3, 4, 5 = the tangents of s, v, e of the last ti_painn_drift_jvp call, same shapes. */
 int ti_painn_debug_tap(ti_handle* h, int stop_after_stage);   /* stage = 0 embed, 1+2l message l, 2+2l update l; -1 = off */
 int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats);
-/* Device self-test of the MFMA operand/accumulator lane maps the kernels rely on. */
+/* Device self-test of the MFMA operand/accumulator lane maps the kernels rely on, and of the fp32 -> (hi, lo) fp16 operand split
+ * (its 8-instruction form against the plain arithmetic, bit for bit). */
 int ti_selftest(int device);
 
 #ifdef __cplusplus

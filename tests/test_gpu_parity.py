@@ -31,7 +31,37 @@ def oracle_from_golden(g):
 
 
 def test_mfma_lane_map_selftest():
+    """ti_selftest: the MFMA lane maps, and the 8-instruction operand split (half-register writes) bit for bit against the plain
+    arithmetic on 16.8 M values at full occupancy."""
     pkg().engine.selftest(0)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2", "f16"])
+def test_parked_geometry_is_per_evaluation(precision):
+    """Layer 0 parks edge_dir and the distance encoding for the later layers of the SAME evaluation (painn_edge_kernel.hpp).  An
+    engine that has evaluated one geometry, a larger batch, and a debug-tap run that stopped half way must give, bit for bit, what
+    a fresh engine gives on the next geometry."""
+    ti = pkg()
+    g = load_golden("ambient_small")
+    mk = lambda: ti.engine.PainnEngine(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                                       g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"],
+                                       precision=precision)
+    rng = np.random.default_rng(5)
+    x1 = g["x"]
+    x2 = (x1 + 0.3 * rng.standard_normal(x1.shape)).astype(np.float32)
+    t = float(g["ts"][1])
+    fresh = mk().drift(x2, t, g["cond"])
+    eng = mk()
+    eng.drift(x1, t, g["cond"])
+    reps = 5                                                   # a larger batch re-allocates the workspace (and the parked buffers)
+    eng.drift(np.tile(x1, (reps, 1, 1)), t, np.tile(g["cond"], (reps,) + (1,) * (g["cond"].ndim - 1)))
+    if precision != "f16":                                     # the storage mode has no taps
+        eng.debug_tap(3)
+        eng.drift(x1, t, g["cond"])
+        eng.debug_tap(-1)
+    again = eng.drift(x2, t, g["cond"])
+    assert np.array_equal(again, fresh)
+    assert not np.array_equal(again, eng.drift(x1, t, g["cond"]))
 
 
 @pytest.mark.parametrize("name", PAINN_CASES)

@@ -221,6 +221,43 @@ __global__ void selftest_kernel(float* out)
     for (int i = 0; i < 16; ++i) out[l * 16 + i] = acc[i];
 }
 
+// Operand-split self-test: Opnd<8, true>::set -- the 8-instruction form with its half-register writes (mfma_chain.hpp: split_quad),
+// eight quads back to back as in the kernels -- against the plain arithmetic, bit for bit, on values spread over 45 binades (exact
+// fp16 values, zeros and fp16-subnormal residuals included).  out[0] counts the halves that differ.
+__global__ void split_selftest_kernel(unsigned* out)
+{
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    r16::Act<8> x;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsigned h = (gid * 32u + nb * 4u + r) * 2654435761u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const int e = (int)(h % 45u) - 30;                                   // 2^-30 .. 2^14
+            const unsigned keep = (h >> 8) % 5u == 0 ? 0x7fe000u : (h >> 8) % 7u == 0 ? 0u : 0x7fffffu;   // some exact fp16 values, some powers of two
+            float v = __builtin_bit_cast(float, (unsigned)((e + 127) << 23) | ((h >> 9) & keep));
+            if ((h >> 3) % 11u == 0) v = 0.f;
+            x.b[nb][r] = (h & 1u) ? -v : v;
+        }
+    r16::Opnd<8, true> o;
+    o.set(x);
+    unsigned bad = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const r16::u32x4 hw = __builtin_bit_cast(r16::u32x4, o.hi[m]), lw = __builtin_bit_cast(r16::u32x4, o.lo[m]);     // registers as dwords
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v0 = x.b[2 * m + (k >> 1)][2 * (k & 1)], v1 = x.b[2 * m + (k >> 1)][2 * (k & 1) + 1];
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            const r16::h2 hr{h0, h1}, lr{(_Float16)((v0 - (float)h0) * 2048.0f), (_Float16)((v1 - (float)h1) * 2048.0f)};
+            const unsigned dh = hw[k] ^ __builtin_bit_cast(unsigned, hr), dl = lw[k] ^ __builtin_bit_cast(unsigned, lr);
+            bad += ((dh & 0xffffu) != 0) + ((dh >> 16) != 0) + ((dl & 0xffffu) != 0) + ((dl >> 16) != 0);
+        }
+    }
+    if (bad) atomicAdd(out, bad);
+}
+
 static inline dim3 grid1(long long n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 hipError_t launch_axpy(float* y, const float* x, float a, const float* b, long long n, hipStream_t st)
@@ -247,6 +284,11 @@ hipError_t launch_scale(float* y, const float* x, float a, long long n, hipStrea
 hipError_t launch_selftest(float* out, hipStream_t st)
 {
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, out);
+    return hipGetLastError();
+}
+hipError_t launch_split_selftest(unsigned* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(split_selftest_kernel, dim3(2048), dim3(256), 0, st, out);      // two workgroups' worth of waves on every CU
     return hipGetLastError();
 }
 hipError_t launch_nan_check(const float* x, long long n, int* flag, hipStream_t st)

@@ -637,18 +637,23 @@ __device__ __forceinline__ float xquarters_max(float v)
 #define TI_SPLIT_REFERENCE 0
 #endif
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h4s __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_quad(const f32x4& v, h4s& hi, h4s& lo)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// v[0..3] -> packed fp16 pairs (hi01, hi23) and their scaled residuals (lo01, lo23), as dwords: the operand registers are assembled
+// from whole dwords, never from single fp16 elements.  (A first form returned 4-element fp16 vectors and inserted them element by
+// element into the 8-element operand registers: correct in every kernel that consumes the registers whole, but a test harness that
+// read single elements back out of them got zeros and copies of element 0 from hipcc -- tools/micro/split_probe.hip stores whole
+// registers for that reason.)
+__device__ __forceinline__ void split_quad(const f32x4& v, unsigned& hi01, unsigned& hi23, unsigned& lo01, unsigned& lo23)
 {
-    hi = h4s{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    hi01 = __builtin_bit_cast(unsigned, h2{(_Float16)v[0], (_Float16)v[1]});
+    hi23 = __builtin_bit_cast(unsigned, h2{(_Float16)v[2], (_Float16)v[3]});
     if constexpr (TI_SPLIT_REFERENCE) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lo[i] = (_Float16)((v[i] - (float)hi[i]) * 2048.0f);
+        const h2 a = __builtin_bit_cast(h2, hi01), b = __builtin_bit_cast(h2, hi23);
+        lo01 = __builtin_bit_cast(unsigned, h2{(_Float16)((v[0] - (float)a[0]) * 2048.0f), (_Float16)((v[1] - (float)a[1]) * 2048.0f)});
+        lo23 = __builtin_bit_cast(unsigned, h2{(_Float16)((v[2] - (float)b[0]) * 2048.0f), (_Float16)((v[3] - (float)b[1]) * 2048.0f)});
     } else {
-        const unsigned ha = __builtin_bit_cast(unsigned, h2{hi[0], hi[1]}), hb = __builtin_bit_cast(unsigned, h2{hi[2], hi[3]});
         const f32x4 s = v * 2048.0f;
         const float c = -2048.0f;
-        unsigned da, db;
         asm("s_nop 0\n\t"
             "v_fma_mixlo_f16 %0, %2, %4, %5 op_sel_hi:[1,0,0]\n\t"
             "v_fma_mixlo_f16 %1, %3, %4, %7 op_sel_hi:[1,0,0]\n\t"
@@ -656,10 +661,8 @@ __device__ __forceinline__ void split_quad(const f32x4& v, h4s& hi, h4s& lo)
             "v_fma_mixhi_f16 %0, %2, %4, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
             "v_fma_mixhi_f16 %1, %3, %4, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
             "s_nop 1"
-            : "=&v"(da), "=&v"(db)
-            : "v"(ha), "v"(hb), "s"(c), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
-        const h2 la = __builtin_bit_cast(h2, da), lb = __builtin_bit_cast(h2, db);
-        lo = h4s{la[0], la[1], lb[0], lb[1]};
+            : "=&v"(lo01), "=&v"(lo23)
+            : "v"(hi01), "v"(hi23), "s"(c), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]));
     }
 }
 
@@ -677,13 +680,12 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
     {
 #pragma unroll
         for (int m = 0; m < NBK / 2; ++m)
-#pragma unroll
-            for (int i = 0; i < 8; i += 4) {
-                h4s h, l;
-                split_quad(i < 4 ? x.b[2 * m] : x.b[2 * m + 1], h, l);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { hi[m][i + r] = h[r]; lo[m][i + r] = l[r]; }
-            }
+        {
+            unsigned h0, h1, h2_, h3, l0, l1, l2, l3;     // element i of the k-step = half i: b[2m][0..3] | b[2m+1][0..3]
+            split_quad(x.b[2 * m], h0, h1, l0, l1);
+            split_quad(x.b[2 * m + 1], h2_, h3, l2, l3);
+            hi[m] = __builtin_bit_cast(h8, u32x4{h0, h1, h2_, h3}); lo[m] = __builtin_bit_cast(h8, u32x4{l0, l1, l2, l3});
+        }
     }
     // For operand sets that are NOT the output of a LayerNorm (the residual streams e, s, v, |Vv|: any magnitude fp32 holds):
     // the row (this lane's 16*NBK values and those of the 3 lanes that share its row) is divided by 2^k, k = exponent of the
@@ -706,13 +708,12 @@ struct Opnd<NBK, true> {                        // split operand: hi and scaled-
         const float inv = __builtin_bit_cast(float, (254u - ec) << 23), scale = __builtin_bit_cast(float, ec << 23);
 #pragma unroll
         for (int m2 = 0; m2 < NBK / 2; ++m2)
-#pragma unroll
-            for (int i = 0; i < 8; i += 4) {
-                h4s h, l;
-                split_quad((i < 4 ? x.b[2 * m2] : x.b[2 * m2 + 1]) * inv, h, l);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { hi[m2][i + r] = h[r]; lo[m2][i + r] = l[r]; }
-            }
+        {
+            unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+            split_quad(x.b[2 * m2] * inv, h0, h1, l0, l1);
+            split_quad(x.b[2 * m2 + 1] * inv, h2_, h3, l2, l3);
+            hi[m2] = __builtin_bit_cast(h8, u32x4{h0, h1, h2_, h3}); lo[m2] = __builtin_bit_cast(h8, u32x4{l0, l1, l2, l3});
+        }
         return scale;
     }
     // Block nb of the set the operand was made from, rebuilt from its halves: (hi + 2^-11 lo) * scale, every step exact, i.e. the

@@ -1512,6 +1512,13 @@ int ti_selftest(int device)
                     return fail(TI_E_HIP, "MFMA 32x32x2 lane map differs from the layout the kernels assume (lane " + std::to_string(l) +
                                               ", reg " + std::to_string(r) + ")");
             }
+        // the 8-instruction operand split (v_fma_mix lo/hi, half-register writes) against the plain arithmetic, 16.8 M values
+        DevBuf<unsigned> cnt; cnt.alloc(1);
+        HIP_CHECK(hipMemset(cnt.p, 0, sizeof(unsigned)));
+        HIP_CHECK(launch_split_selftest(cnt.p, nullptr));
+        unsigned bad = 0;
+        HIP_CHECK(hipMemcpy(&bad, cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (bad) return fail(TI_E_HIP, "operand split: " + std::to_string(bad) + " fp16 halves differ from the reference arithmetic");
         return TI_OK;
     });
 }

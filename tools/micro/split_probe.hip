@@ -1,71 +1,81 @@
-// split_probe.hip -- do the two forms of the fp32 -> (hi, 2^11 lo) fp16 split (mfma_chain.hpp: split_pair) give the same bits?
-//   hipcc --offload-arch=gfx950 -O3 -o tools/micro/split_probe tools/micro/split_probe.hip && tools/micro/split_probe
-// Values span 2^-40 .. 2^15 with random mantissas; reports, per binade of |2^11 (v - hi)|, how many lo halves differ and the
-// largest |difference| of the reconstructed value hi + 2^-11 lo.
+// split_probe.hip -- the product's operand split (mfma_chain.hpp: Opnd<8, true>::set -> split_quad, 8 vector instructions per four
+// values, half-register writes) against the plain arithmetic, bit for bit.  The two forms run in SEPARATE kernels on the same
+// generated values (nothing of one can be scheduled into or folded with the other) and the host compares the fp16 halves.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I thermodynamic-interpolation_amd/csrc -o tools/micro/split_probe tools/micro/split_probe.hip
 #include <hip/hip_runtime.h>
-#include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <vector>
 
-__global__ void probe(const float* v, unsigned short* hi, unsigned short* lo_ref, unsigned short* lo_mix, int n)
+#include "mfma_chain.hpp"
+
+using namespace ti;
+
+__device__ __forceinline__ void make_values(unsigned gid, r16::Act<8>& x)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (2 * i + 1 >= n) return;
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const float v0 = v[2 * i], v1 = v[2 * i + 1];
-    const h2 h = h2{(_Float16)v0, (_Float16)v1};
-    const h2 lr = h2{(_Float16)((v0 - (float)h[0]) * 2048.0f), (_Float16)((v1 - (float)h[1]) * 2048.0f)};
-    const unsigned hb = __builtin_bit_cast(unsigned, h);
-    const float s0 = v0 * 2048.0f, s1 = v1 * 2048.0f, c = -2048.0f;
-    unsigned d;
-    asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "s"(c), "v"(s0));
-    asm volatile("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hb), "s"(c), "v"(s1));
-    const unsigned r = __builtin_bit_cast(unsigned, lr);
-    hi[2 * i] = hb & 0xffff; hi[2 * i + 1] = hb >> 16;
-    lo_ref[2 * i] = r & 0xffff; lo_ref[2 * i + 1] = r >> 16;
-    lo_mix[2 * i] = d & 0xffff; lo_mix[2 * i + 1] = d >> 16;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsigned h = (gid * 32u + nb * 4u + r) * 2654435761u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const int e = (int)(h % 45u) - 30;                                   // 2^-30 .. 2^14
+            const unsigned keep = (h >> 8) % 5u == 0 ? 0x7fe000u : (h >> 8) % 7u == 0 ? 0u : 0x7fffffu;   // exact fp16 values, powers of two
+            float v = __builtin_bit_cast(float, (unsigned)((e + 127) << 23) | ((h >> 9) & keep));
+            if ((h >> 3) % 11u == 0) v = 0.f;
+            x.b[nb][r] = (h & 1u) ? -v : v;
+        }
 }
 
-static float h2f(unsigned short h)
+__global__ void split_product(unsigned short* hi, unsigned short* lo)
 {
-    const int s = h >> 15, e = (h >> 10) & 31, m = h & 1023;
-    float x = e == 0 ? std::ldexp((float)m, -24) : e == 31 ? INFINITY : std::ldexp((float)(m + 1024), e - 25);
-    return s ? -x : x;
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    r16::Act<8> x;
+    make_values(gid, x);
+    r16::Opnd<8, true> o;
+    o.set(x);
+    // whole registers, as the matrix instructions consume them (16-byte stores; element i of k-step m is half i of register m)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        reinterpret_cast<r16::h8*>(hi)[(size_t)gid * 4 + m] = o.hi[m];
+        reinterpret_cast<r16::h8*>(lo)[(size_t)gid * 4 + m] = o.lo[m];
+    }
+}
+
+__global__ void split_plain(unsigned short* hi, unsigned short* lo, float* vals)
+{
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    r16::Act<8> x;
+    make_values(gid, x);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = i < 4 ? x.b[2 * m][i] : x.b[2 * m + 1][i - 4];
+            const _Float16 h = (_Float16)v, l = (_Float16)((v - (float)h) * 2048.0f);
+            hi[(size_t)gid * 32 + m * 8 + i] = __builtin_bit_cast(unsigned short, h);
+            lo[(size_t)gid * 32 + m * 8 + i] = __builtin_bit_cast(unsigned short, l);
+            vals[(size_t)gid * 32 + m * 8 + i] = v;
+        }
 }
 
 int main()
 {
-    const int n = 1 << 20;
-    std::vector<float> v(n);
-    srand(1);
-    for (int i = 0; i < n; ++i) {
-        const int e = rand() % 56 - 40;
-        v[i] = std::ldexp(1.0f + (rand() & 0x7fffff) / 8388608.0f, e) * ((rand() & 1) ? -1.f : 1.f);
+    const int blocks = 2048, threads = 256;
+    const size_t n = (size_t)blocks * threads * 32;
+    unsigned short *h1, *l1, *h2, *l2; float* vals;
+    hipMalloc((void**)&h1, n * 2); hipMalloc((void**)&l1, n * 2); hipMalloc((void**)&h2, n * 2); hipMalloc((void**)&l2, n * 2); hipMalloc((void**)&vals, n * 4);
+    split_product<<<blocks, threads>>>(h1, l1);
+    split_plain<<<blocks, threads>>>(h2, l2, vals);
+    std::vector<unsigned short> a(n), b(n), c(n), d(n); std::vector<float> v(n);
+    hipMemcpy(a.data(), h1, n * 2, hipMemcpyDeviceToHost); hipMemcpy(b.data(), l1, n * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(c.data(), h2, n * 2, hipMemcpyDeviceToHost); hipMemcpy(d.data(), l2, n * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(v.data(), vals, n * 4, hipMemcpyDeviceToHost);
+    size_t bad_hi = 0, bad_lo = 0, sub = 0, shown = 0;
+    for (size_t i = 0; i < n; ++i) {
+        bad_hi += a[i] != c[i];
+        if (b[i] != d[i]) { ++bad_lo; if (shown++ < 8) printf("  v = %a: lo product %04x plain %04x (hi %04x / %04x), element %zu of its lane\n", v[i], b[i], d[i], a[i], c[i], i % 32); }
+        sub += (d[i] & 0x7c00) == 0 && (d[i] & 0x3ff) != 0;
     }
-    float* dv; unsigned short *dh, *dr, *dm;
-    hipMalloc(&dv, n * 4); hipMalloc(&dh, n * 2); hipMalloc(&dr, n * 2); hipMalloc(&dm, n * 2);
-    hipMemcpy(dv, v.data(), n * 4, hipMemcpyHostToDevice);
-    probe<<<n / 2 / 256, 256>>>(dv, dh, dr, dm, n);
-    std::vector<unsigned short> hi(n), lr(n), lm(n);
-    hipMemcpy(hi.data(), dh, n * 2, hipMemcpyDeviceToHost); hipMemcpy(lr.data(), dr, n * 2, hipMemcpyDeviceToHost);
-    hipMemcpy(lm.data(), dm, n * 2, hipMemcpyDeviceToHost);
-    long differ = 0, differ_normal = 0, mix_zero_ref_sub = 0, ref_sub = 0;
-    double worst = 0, worst_rel = 0;
-    for (int i = 0; i < n; ++i) {
-        const float a = h2f(lr[i]), b = h2f(lm[i]);
-        const bool sub = (lr[i] & 0x7c00) == 0 && (lr[i] & 0x3ff) != 0;
-        ref_sub += sub;
-        if (lr[i] != lm[i]) {
-            ++differ;
-            if (!sub) ++differ_normal;
-            if (sub && (lm[i] & 0x7fff) == 0) ++mix_zero_ref_sub;
-            const double dabs = std::fabs((double)a - b) / 2048.0;
-            worst = std::max(worst, dabs); worst_rel = std::max(worst_rel, dabs / std::fabs(v[i]));
-        }
-    }
-    printf("values %d: lo halves that differ %ld (of them with a NORMAL reference lo: %ld); reference lo subnormal %ld, mix form 0 there %ld\n", n,
-           differ, differ_normal, ref_sub, mix_zero_ref_sub);
-    printf("largest |difference| of hi + 2^-11 lo: %.3e absolute, %.3e relative to |v|\n", worst, worst_rel);
-    return 0;
+    printf("values %zu: hi halves that differ %zu, lo halves that differ %zu (plain lo fp16-subnormal: %zu)\n", n, bad_hi, bad_lo, sub);
+    return bad_hi || bad_lo ? 1 : 0;
 }
