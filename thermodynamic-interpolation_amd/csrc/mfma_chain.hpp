@@ -436,7 +436,7 @@ __device__ __forceinline__ void load_set(Act<NBK>& a, const float* p, int q)
 }
 
 template <int NBK>
-__device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const float* beta, int q)
+__device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const float* beta, int q, float eps = 1e-5f)
 {
     constexpr float invF = 1.0f / (16.0f * NBK);
     float sum = 0.f;
@@ -451,7 +451,7 @@ __device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const f
             const float d = a.b[nb][r] - mean;
             var = fmaf(d, d, var);
         }
-    const float rstd = rsqrt_nr(xquarters(var) * invF + 1e-5f);
+    const float rstd = rsqrt_nr(xquarters(var) * invF + eps);
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
         const f32x4 gm = load_block(gamma, nb, q), bt = load_block(beta, nb, q);
@@ -774,6 +774,93 @@ __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd<NBK
     gemm_split_chunk<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane);
 }
 // ---------------------------------------------------------------------------------------------------------------------
+// One accumulator chain (message kernel, TI_PREC_F16X2).  The 2^11 on the residual halves of Opnd<NBK, true> is there to keep them out
+// of the fp16 subnormal range, and it is why the cross terms need their own accumulator and a v_fma per output element to fold it
+// back.  v_mfma_f32_16x16x32_f16 takes subnormal inputs at face value (tools/micro/mfma_denorm.hip), so here
+//   * the WEIGHTS of each matrix are scaled on the host by a power of two S to the top of the fp16 range (max |S w| in [2^13, 2^14):
+//     hi = fp16(S w), lo = fp16(S w - hi) is a normal number for every weight within 2^-16 of the matrix's largest), ti_api.hip;
+//   * ACTIVATIONS are split unscaled: hi = fp16(x), lo = fp16(x - hi).  Their rows are LayerNorm / SiLU outputs, encodings or rows
+//     normalised by set_scaled: a residual below 2^-14 is resolved to 2^-24, fp32 rounding level for such a row;
+//   * hi.hi, hi.lo and lo.hi accumulate into ONE register set, which then holds S times the product: S cancels in the LayerNorm that
+//     follows (epsilon scaled by S^2, biases by S) or is folded into factors the consumer multiplies with anyway.
+template <int NBK>
+struct Opnd1 {
+    h8 hi[NBK / 2], lo[NBK / 2];
+    __device__ __forceinline__ static void quad(const f32x4& v, unsigned& hi01, unsigned& hi23, unsigned& lo01, unsigned& lo23)
+    {
+        hi01 = __builtin_bit_cast(unsigned, h2{(_Float16)v[0], (_Float16)v[1]});
+        hi23 = __builtin_bit_cast(unsigned, h2{(_Float16)v[2], (_Float16)v[3]});
+        // fp16(fma(f32(hi), -1, v)) = fp16(v - hi): exact difference, one rounding; half-register writes fenced as in split_quad
+        asm("s_nop 0\n\t"
+            "v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+            "s_nop 0\n\t"
+            "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "s_nop 1"
+            : "=&v"(lo01), "=&v"(lo23)
+            : "v"(hi01), "v"(hi23), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    }
+    __device__ __forceinline__ void set(const Act<NBK>& x)
+    {
+#pragma unroll
+        for (int m = 0; m < NBK / 2; ++m) {
+            unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+            quad(x.b[2 * m], h0, h1, l0, l1);
+            quad(x.b[2 * m + 1], h2_, h3, l2, l3);
+            hi[m] = __builtin_bit_cast(h8, u32x4{h0, h1, h2_, h3}); lo[m] = __builtin_bit_cast(h8, u32x4{l0, l1, l2, l3});
+        }
+    }
+    // un-normalised rows (e): divided by the power of two of the row maximum first (as Opnd<NBK, true>::set_scaled), which is returned
+    __device__ __forceinline__ float set_scaled(const Act<NBK>& x)
+    {
+        float m = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x.b[nb][r]));
+        m = xquarters_max(m);
+        const unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;
+        const unsigned ec = e < 64u ? 127u : e > 190u ? 190u : e;
+        const float inv = __builtin_bit_cast(float, (254u - ec) << 23), scale = __builtin_bit_cast(float, ec << 23);
+#pragma unroll
+        for (int m2 = 0; m2 < NBK / 2; ++m2) {
+            unsigned h0, h1, h2_, h3, l0, l1, l2, l3;
+            quad(x.b[2 * m2] * inv, h0, h1, l0, l1);
+            quad(x.b[2 * m2 + 1] * inv, h2_, h3, l2, l3);
+            hi[m2] = __builtin_bit_cast(h8, u32x4{h0, h1, h2_, h3}); lo[m2] = __builtin_bit_cast(h8, u32x4{l0, l1, l2, l3});
+        }
+        return scale;
+    }
+};
+// chunk image as for gemm_split_chunk ([step][hi | lo][lane]); three products per step into the one accumulator of the step's output block
+template <int NBK, bool FLIP>
+__device__ __forceinline__ void gemm_split_chunk1(f32x4& acc0, f32x4& acc1, const Opnd1<NBK>& in, const h8* wl, int lane)
+{
+    constexpr int KS = NBK / 2, STEPS = 2 * KS, AH = TI_FRAG_AHEAD < STEPS ? TI_FRAG_AHEAD : STEPS;
+    h8 fh[AH + 1], fl[AH + 1];
+#pragma unroll
+    for (int s = 0; s < AH; ++s) { fh[s] = wl[(2 * s) * 64 + lane]; fl[s] = wl[(2 * s + 1) * 64 + lane]; }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + AH < STEPS) {
+            fh[(s + AH) % (AH + 1)] = wl[(2 * (s + AH)) * 64 + lane];
+            fl[(s + AH) % (AH + 1)] = wl[(2 * (s + AH) + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0x16);
+        const h8 wh = fh[s % (AH + 1)], wlo = fl[s % (AH + 1)];
+        const int m = s % KS;
+        f32x4& acc = s < KS ? acc0 : acc1;
+        if (FLIP) { acc = mfma16h(in.hi[m], wh, acc); acc = mfma16h(in.lo[m], wh, acc); acc = mfma16h(in.hi[m], wlo, acc); }
+        else      { acc = mfma16h(wh, in.hi[m], acc); acc = mfma16h(wh, in.lo[m], acc); acc = mfma16h(wlo, in.hi[m], acc); }
+        __builtin_amdgcn_sched_barrier(0x16);
+    }
+}
+template <int NBK>
+__device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd1<NBK>& in, const f32x4* wl4, int lane) { gemm_split_chunk1<NBK, false>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
+template <int NBK>
+__device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd1<NBK>& in, const f32x4* wl4, int lane) { gemm_split_chunk1<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
+// ---------------------------------------------------------------------------------------------------------------------
 // fp16-storage mode (include/ti_hip.h TI_PREC_F16; BASELINE.json configs[4] "fp16 node features with MFMA linears"): the state
 // tensors s, v, P, e live in HBM as fp16, every matrix product is ONE v_mfma_f32_16x16x32_f16 per 32-wide k-step on the fp16
 // rounding of its operands (weights: a hi-only image, half the bytes per chunk through LDS), accumulation,
@@ -926,10 +1013,10 @@ struct QuarterSum {
     static_assert(NS == 2 || NS == 4, "2 or 4 slots per row block");
     float msk[NS][4];
     __device__ __forceinline__ static constexpr int slot_of_quarter(int q) { return NS == 2 ? (q & 1) : q; }
-    __device__ __forceinline__ void set_row(int r, int slot)
+    __device__ __forceinline__ void set_row(int r, int slot, float one = 1.0f)     // `one`: a common factor of the summed values, applied here for free
     {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) msk[k][r] = slot == k ? 1.0f : 0.0f;
+        for (int k = 0; k < NS; ++k) msk[k][r] = slot == k ? one : 0.0f;
     }
     __device__ __forceinline__ float partial(int k, const f32x4& v) const
     {

@@ -50,6 +50,10 @@ __device__ __forceinline__ void acc_out(float* p, float v, bool first)
 __host__ __device__ constexpr int edge_superchunk(int NB, int WAVES, bool H16 = false) { return ((WAVES == 8 && NB == 4) ? 4 : 2) * (H16 && NB == 4 ? 2 : 1); }
 __host__ __device__ constexpr int edge_chunk4(int NB, bool H16) { return (H16 ? 128 : 256) * NB; }            // float4 per weight chunk
 // F = 32 in the storage mode: a 2-chunk superchunk (4 KB) is smaller than one 16-byte lane per thread of the 8-wave build
+// Does this (feature width, precision) run the one-accumulator split format (mfma_chain.hpp: Opnd1)?  TI_PREC_F16X2 up to F = 128.  The
+// F = 256 build of it (one wave per SIMD, operands partly in AGPRs) faulted on the device in the first GPU run and keeps the
+// two-accumulator format until that is understood; ti_api.hip packs the message streams accordingly.
+__host__ __device__ constexpr bool edge_one_chain(int NB, int PREC) { return PREC == 1 && NB <= 4; }
 __host__ __device__ constexpr bool edge_build_exists(int NB, int WAVES, int PREC) { return !(PREC == 2 && NB == 1 && WAVES == 8); }
 template <int NBK, bool FIRST, bool LAST, int PREC, int WAVES, int NS>
 __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)
@@ -57,7 +61,10 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
     constexpr bool H16 = PREC == 2;                 // fp16 state tensors, hi-only weight chunks
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = edge_chunk4(NB, H16);
     using A16 = r16::Act<NBK>;
-    using OP = typename r16::OpSel<NBK, PREC>::type;
+    // split-fp16 path: the one-accumulator operand / weight format (mfma_chain.hpp: Opnd1; weights scaled per matrix, p.wscale)
+    // (F <= 128 only: edge_one_chain)
+    constexpr bool ONE = edge_one_chain(NB, PREC);
+    using OP = std::conditional_t<ONE, r16::Opnd1<NBK>, typename r16::OpSel<NBK, PREC>::type>;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
     constexpr int SC = edge_superchunk(NB, WAVES, H16);                             // weight chunks per barrier
@@ -68,6 +75,12 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
     PipeDMA<NB, T, SC, CH4> pipe;                                                // weights staged SC chunks per barrier
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);   // barrier inside: vec is visible after it
 
+    // ONE: accumulators hold S times the product, S = the power of two the host scaled that matrix by (ti_api.hip).  S cancels in
+    // the LayerNorm behind a hidden layer (epsilon * S^2; the bias rows of `vec` are already scaled); the output products carry
+    // S_phi2 * S_w2, divided out in the row masks of the per-atom sums and in the e update.
+    const float eps_w0 = ONE ? 1e-5f * p.wscale[0] * p.wscale[0] : 1e-5f, eps_w1 = ONE ? 1e-5f * p.wscale[1] * p.wscale[1] : 1e-5f;
+    const float eps_p0 = ONE ? 1e-5f * p.wscale[2] * p.wscale[2] : 1e-5f, eps_p1 = ONE ? 1e-5f * p.wscale[3] * p.wscale[3] : 1e-5f;
+    const float s_p0 = ONE ? p.wscale[2] : 1.0f, inv_out = ONE ? 1.0f / (p.wscale[4] * p.wscale[5]) : 1.0f;
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
-            r16::ln_silu(t1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q);
+            r16::ln_silu(t1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q, eps_w0);
             g1.set(t1);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
-            r16::ln_silu(t1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q);
+            r16::ln_silu(t1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q, eps_w1);
             g2.set(t1);
         }
         // ---- phi([s[src] | e]) hidden layers; the s[src] half of the first Linear is P[src] (node kernels)
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                 else       r16::load_set(t1, p.e + (erow0 + j) * F, q);
                 e_scale = ein.set_scaled(t1);                                  // e is an un-normalised stream: per-row 2^k
             }
-            const float e_inv = r16::pow2_inverse(e_scale);
+            const float e_inv = r16::pow2_inverse(e_scale) * s_p0;           // (the matrix scale of phi layer 0 rides on the accumulator init)
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 // P[src] (the s[src] half of the Linear) / 2^k + W e' of the scaled rows, then * 2^k: all exact scalings
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
-            r16::ln_silu(t1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q);
+            r16::ln_silu(t1, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q, eps_p0);
             h1.set(t1);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
-            r16::ln_silu(t1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q);
+            r16::ln_silu(t1, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q, eps_p1);
             h2.set(t1);
         }
         // ---- output layer, flipped: features on lanes (l & 15), the block's rows 4q + r in registers
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
         // instruction carries the sums of every slot of the block.  qnode is the atom this quarter adds to (or -1).
         r16::QuarterSum<NS> qs;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qs.set_row(r, row_slot(mi[r]));
+        for (int r = 0; r < 4; ++r) qs.set_row(r, row_slot(mi[r]), inv_out);
         int qnode;
         bool qfirst;                                 // first block of that atom: replace the accumulator instead of adding (ti_internal.hpp)
         {
@@ -252,8 +265,8 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
                     if (group_ok) {
                         if (FIRST) {
                             const float* em = p.edge_emb + row_type(mi[r]) * F + fo;
-                            ep[0] = em[0] + v0[r]; ep[16] = em[16] + v1[r];
-                        } else { add_noret(ep, v0[r]); add_noret(ep + 16, v1[r]); }
+                            ep[0] = em[0] + v0[r] * inv_out; ep[16] = em[16] + v1[r] * inv_out;
+                        } else { add_noret(ep, v0[r] * inv_out); add_noret(ep + 16, v1[r] * inv_out); }
                     }
                 }
             }

@@ -60,6 +60,36 @@ void pack_chunk16_split(std::vector<float>& dst, const float* W, int ld, int n_r
                 }
 }
 
+// one-accumulator format of the message kernel (mfma_chain.hpp: Opnd1 / gemm_split_chunk1): the matrix is scaled by the power of two S
+// first and the residual is NOT scaled:  hi = fp16(S w), lo = fp16(S w - hi).  Same layout and size as pack_chunk16_split.
+void pack_chunk16_split1(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBK, float S)
+{
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)2 * NBK * 64 * 4);
+    _Float16* out = reinterpret_cast<_Float16*>(dst.data() + base);
+    const int KS = NBK / 2;
+    for (int blk = 0; blk < 2; ++blk)
+        for (int m = 0; m < KS; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 8; ++i) {
+                    const int row = row0 + 16 * blk + (l & 15), col = col0 + 16 * (2 * m + (i >> 2)) + 4 * (l >> 4) + (i & 3);
+                    const float w = (row < n_rows ? W[(size_t)row * ld + col] : 0.f) * S;
+                    const _Float16 h = (_Float16)w;
+                    out[((size_t)((blk * KS + m) * 2 + 0) * 64 + l) * 8 + i] = h;
+                    out[((size_t)((blk * KS + m) * 2 + 1) * 64 + l) * 8 + i] = (_Float16)(w - (float)h);
+                }
+}
+// power of two that brings the largest |entry| of W[0..rows)[col0..col0+cols) into [2^13, 2^14)   (1 for an all-zero matrix)
+float matrix_pow2_scale(const float* W, int ld, int rows, int col0, int cols)
+{
+    float mx = 0.f;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) mx = std::max(mx, std::fabs(W[(size_t)r * ld + col0 + c]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    int e; std::frexp(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.0f, std::min(60, std::max(-60, 14 - e)));
+}
+
 // fp16 storage mode (r16::OpndH): the hi fragments alone, half the bytes:  frag[(blk*(NBK/2) + m)*64 + l][i]
 void pack_chunk16_half(std::vector<float>& dst, const float* W, int ld, int n_rows, int row0, int col0, int NBK)
 {
@@ -120,7 +150,7 @@ struct ti_handle {
     int NB = 0, nE = 0, ncond = 0, G = 1, nblk = 0;
     MlpOff embed{}, readout{}; std::vector<MlpOff> phi, w, upd; std::vector<size_t> U, V;
     size_t edge_emb = 0, atom_emb = 0, Vr = 0; float b2_gate = 0.f;
-    Stream st_embed16{}; std::vector<Stream> st_edge, st_update;
+    Stream st_embed16{}; std::vector<Stream> st_edge, st_edge1, st_update;      // st_edge1: the message kernel's one-accumulator format (TI_PREC_F16X2)
     // edge templates (ti_internal.hpp): [0] throughput (G molecules per group), [1] latency (G = 1, P parts per molecule);
     // G / P / nblk / rows / slotnode below are those of the ACTIVE one (select_template, once per API call)
     struct Tpl {
@@ -137,7 +167,8 @@ struct ti_handle {
     struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
     DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
-    DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, enc, geo, b1, b2, xt, edge_vecs, upd_vecs;
+    DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, enc, geo, b1, b2, xt, edge_vecs, edge_vecs1, upd_vecs;
+    std::vector<float> edge_scale;               // [L][6] per-matrix powers of two of the one-accumulator message streams (TI_PREC_F16X2)
     int tap = -1; long long last_B = 0;
     // forward-mode derivative (painn_jvp_kernels.hip): tangent twins over virtual molecules, sized on first use
     std::vector<Stream> st_jvp_update, st_jvp_phi; Stream st_jvp_readout{}; std::vector<int> jvp_phi_pad;
@@ -390,6 +421,25 @@ void pack_painn(ti_handle* h, const float* wts)
                 chunk16(h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0);
             }
         h->st_edge.push_back(end_stream16(o));
+        if (edge_uses_one_chain(NB, prec)) {         // the same chunks in the one-accumulator format, each matrix scaled by its own power of two
+            const float S[6] = {matrix_pow2_scale(wts + h->w[l].W0, F, F, 0, F), matrix_pow2_scale(wts + h->w[l].W1, F, F, 0, F),
+                                matrix_pow2_scale(wts + h->phi[l].W0, 2 * F, F, F, F), matrix_pow2_scale(wts + h->phi[l].W1, F, F, 0, F),
+                                matrix_pow2_scale(wts + h->phi[l].W2, F, 5 * F, 0, F), matrix_pow2_scale(wts + h->w[l].W2, F, 5 * F, 0, F)};
+            auto layer1 = [&](size_t W, int ld, int n_rows, int col0, float sc) { for (int nbo = 0; nbo < NB; ++nbo) pack_chunk16_split1(pk, wts + W, ld, n_rows, 32 * nbo, col0, NBK, sc); };
+            o = begin_stream();
+            layer1(h->w[l].W0, F, F, 0, S[0]); layer1(h->w[l].W1, F, F, 0, S[1]);
+            layer1(h->phi[l].W0, 2 * F, F, F, S[2]);
+            layer1(h->phi[l].W1, F, F, 0, S[3]);
+            for (int nbo = 0; nbo < NB; ++nbo)
+                for (int c : {2, 3, 1, 0, 4}) {
+                    if (c == 3 && last) continue;
+                    if ((c == 0 || c == 4) && first) continue;
+                    pack_chunk16_split1(pk, wts + h->phi[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NBK, S[4]);
+                    pack_chunk16_split1(pk, wts + h->w[l].W2, F, 5 * F, c * F + 32 * nbo, 0, NBK, S[5]);
+                }
+            h->st_edge1.push_back(end_stream16(o));
+            h->edge_scale.insert(h->edge_scale.end(), S, S + 6);
+        }
         o = begin_stream();                          // update kernel: 16-row chunk format, order of painn_update_kernel
         layer16(h->V[l], F, F, 0);                                                    // phase A (3 components per visit)
         layer16(h->upd[l].W0, 2 * F, F, 0); layer16(h->upd[l].W0, 2 * F, F, F);      // MLP L1: |vv| part, s part
@@ -459,6 +509,16 @@ void pack_painn(ti_handle* h, const float* wts)
         ev.insert(ev.end(), wts + w.b2, wts + w.b2 + 5 * F);
     }
     h->edge_vecs.upload(ev);
+    if (edge_uses_one_chain(NB, prec)) {             // the message kernel's copy: bias rows times the scale of their matrix (EV order: W_B0 = 0, W_B1 = 3, P_B1 = 8, P_B2 = 11..15, W_B2 = 16..20)
+        std::vector<float> ev1 = ev;
+        for (int l = 0; l < L; ++l) {
+            const float* S = h->edge_scale.data() + (size_t)l * 6;
+            float* b = ev1.data() + (size_t)l * 21 * F;
+            auto mul = [&](int row, int n, float sc) { for (int i = 0; i < n * F; ++i) b[(size_t)row * F + i] *= sc; };
+            mul(0, 1, S[0]); mul(3, 1, S[1]); mul(8, 1, S[3]); mul(11, 5, S[4]); mul(16, 5, S[5]);
+        }
+        h->edge_vecs1.upload(ev1);
+    }
     std::vector<float> uv;                           // order = struct UV in painn_kernels.hip
     for (int l = 0; l < L; ++l) {
         const MlpOff& u = h->upd[l];
@@ -609,6 +669,11 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
             p.edge_emb = h->F(h->edge_emb); p.rows = h->rows.p; p.slotnode = h->slotnode.p; p.nslots = nullptr;
             p.nblk = h->nblk; p.G = h->G; p.parts = h->parts; p.A = A; p.max_slots = h->max_slots; p.B = B; p.n_groups = groups; p.length_scale = h->d.length_scale;
             p.x = x_dev; p.P = h->P.p; p.v = h->v.p; p.dsacc = h->dsacc.p; p.dvacc = h->dvacc.p; p.cacc = h->cacc.p; p.e = h->e.p; p.enc = h->enc.p; p.geo = h->geo.p;
+            for (int i = 0; i < 6; ++i) p.wscale[i] = 1.0f;
+            if (edge_uses_one_chain(NB, prec)) {     // the message kernel's own stream format (the primal pass of the divergence keeps the other one)
+                p.stream = h->S(h->st_edge1[l]); p.nch = h->st_edge1[l].nch; p.vecs = h->edge_vecs1.p + (size_t)l * 21 * F;
+                for (int i = 0; i < 6; ++i) p.wscale[i] = h->edge_scale[(size_t)l * 6 + i];
+            }
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
             HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
         }

@@ -58,6 +58,7 @@ struct EdgeParams {
     float* cacc;                            // [B*A][3][F] += sum cg*dir   (crossed with v[dst] in the update kernel)
     float* e;                               // [n_groups*nblk*16][F]
     float* enc;                             // [n_groups*nblk][operand registers][64] parked encoding operand of every row block (layer 0 writes, the others read)
+    float wscale[6];                        // TI_PREC_F16X2: powers of two the host scaled w.W0, w.W1, phi.W0(e), phi.W1, phi.W2, w.W2 by (else 1)
     float* geo;                             // [n_groups*nblk*16][4] parked edge_dir
 };
 
@@ -90,6 +91,7 @@ struct ReadoutParams {
 // prec = TI_PREC_* of include/ti_hip.h; with TI_PREC_F16 the state tensors s, P, v, e behind the float* fields are fp16
 hipError_t launch_embed(int NB, int nseg, int prec, const EmbedParams& p, hipStream_t st);
 hipError_t launch_edge(int NB, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st);
+bool edge_uses_one_chain(int NB, int prec);      // message kernel on the one-accumulator split format (painn_edge_kernel.hpp: edge_one_chain)
 hipError_t launch_update(int NB, bool has_next, int prec, const UpdateParams& p, hipStream_t st);
 hipError_t launch_readout(int NB, int prec, const ReadoutParams& p, hipStream_t st);
 hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes
