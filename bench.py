@@ -210,7 +210,7 @@ def main():
         rec = {
             "metric": "integration-steps/sec (whole node) + drift rel-L2 vs CPU ref", "value": value, "unit": "trajectory-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 state and accumulation; matrix products on fp16 MFMA with 2-way split fp32 operands (hi + 2^-11 lo, 3 products)" if split else "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 state and accumulation; matrix products on fp16 MFMA with 2-way split fp32 operands (hi + lo halves, 3 products)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"mdqm9 ambient sampler: {B} molecules/GPU x 18 atoms (fully connected, 306 edges), cPaiNN F=128 L=5, "
                                    "Euler-Maruyama steps of the 1000-step grid, T1 over a 6-rung ladder",
                        "trajectories_per_gpu": B, "atoms": A, "n_features": F, "score_layers": L, "scheme": "em", "eps": args.eps,
