@@ -26,8 +26,8 @@
  *     the handle's device (e.g. torch.Tensor.data_ptr()); device work is enqueued on the handle's stream and the
  *     call returns after that stream has been synchronised.
  *   - There is no CPU fallback: if no gfx950 device is usable, create() fails with TI_E_HIP.
- *   - Environment (read per call): TI_TEMPLATE=throughput|latency pins the edge-row layout that is otherwise chosen from the
- *     batch size (results agree to fp32 round-off; bit-identical within one layout); TI_JVP_WS_GB = HBM budget in GB for the
+ *   - Environment (read per call): TI_TEMPLATE=throughput|latency|pair pins the edge-row layout that is otherwise chosen from
+ *     the batch size (results agree to fp32 round-off; bit-identical within one layout); TI_JVP_WS_GB = HBM budget in GB for the
  *     tangent state of the divergence (default 48).
  *
  * Weight layout ("canonical flat layout", fp32 unless noted; every tensor row-major in torch's [out, in] order)
@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TI_ABI_VERSION 3
+#define TI_ABI_VERSION 4
 
 enum { TI_OK = 0, TI_E_ARG = -1, TI_E_HIP = -2, TI_E_NAN = -3, TI_E_ALLOC = -4, TI_E_UNSUPPORTED = -5 };
 enum { TI_MEM_HOST = 0, TI_MEM_DEVICE = 1 };
@@ -87,10 +87,18 @@ typedef struct ti_painn_desc {
     float   length_scale;   /* ... for edge distances (reference: 10) */
     float   temp_mean;      /* mean(temperatures)            (embedding.py:209) */
     float   temp_range;     /* max(temperatures) - min(...)  (embedding.py:210) */
-    int32_t precision;      /* TI_PREC_F32: f32 MFMA (default); TI_PREC_F16X2: the message MLPs' matrix products on the fp16
-                               matrix rate with every fp32 operand split into two fp16 halves (hi + 2^-11 lo; products
-                               hi*hi, hi*lo, lo*hi; fp32 accumulation; ~24 significand bits; un-normalised operand rows are
-                               scaled by a power of two first, so any fp32 magnitude works; weights must be < 65504);
+    int32_t precision;      /* TI_PREC_F32: f32 MFMA (default); TI_PREC_F16X2: the matrix products on the fp16 matrix rate with
+                               every fp32 operand split into two fp16 halves (products hi*hi, hi*lo, lo*hi; fp32 accumulation;
+                               ~24 significand bits; un-normalised operand rows are scaled by a power of two first, so any fp32
+                               magnitude works; weights must be < 65504).  Two operand formats are in use:
+                                 (a) "two accumulators": x = hi + 2^-11 lo with lo = fp16(2^11 (x - hi)); the cross terms have an
+                                     accumulator of their own that is folded back with 2^-11.  Used by the update / embed / readout /
+                                     tangent kernels at every width and by the message kernels at F = 256;
+                                 (b) "one accumulator" (message kernels, F <= 128): each weight matrix is scaled on the host by a
+                                     power of two S to the top of the fp16 range, lo = fp16(S w - hi) and lo = fp16(x - hi) are NOT
+                                     scaled, and all three products add into one register set (S cancels in the LayerNorm behind
+                                     a hidden layer and is divided out of the output products).  It relies on
+                                     v_mfma_f32_16x16x32_f16 taking fp16-subnormal inputs at face value, which ti_selftest checks;
                                TI_PREC_F16: fp16 STORAGE mode (BASELINE.json configs[4]): the state tensors s, v, P, e live in HBM
                                as fp16 and every matrix product is one fp16 MFMA with fp32 accumulation; LayerNorm, SiLU,
                                sin/cos, per-atom sums and the integrator state x stay fp32.  A separately labelled precision:
@@ -184,12 +192,15 @@ enum { TI_STREAM_OWN = 0, TI_STREAM_EXTERNAL = 1 };
 int ti_set_stream(ti_handle* h, void* hip_stream, int mode);
 int ti_wait_stream(ti_handle* h, void* producer_stream);
 /* Pin the edge-row layout of a painn handle: TI_TEMPLATE_AUTO (from the batch size of each call, the default),
- * TI_TEMPLATE_THROUGHPUT or TI_TEMPLATE_LATENCY.  Results are bit-identical within one layout and agree to fp32 round-off
- * across them, so a run sharded over ranks pins the layout it would use for the GLOBAL batch and becomes independent of
- * the rank count.  (The TI_TEMPLATE environment variable, read per call, overrides this.) */
-enum { TI_TEMPLATE_AUTO = -1, TI_TEMPLATE_THROUGHPUT = 0, TI_TEMPLATE_LATENCY = 1 };
+ * TI_TEMPLATE_THROUGHPUT, TI_TEMPLATE_LATENCY (directed edge rows sorted by destination) or TI_TEMPLATE_PAIR (pair-major rows:
+ * the filter branch w(enc(|r_ij|)) of SE3Message, cpainn.py:283-289, is evaluated once per atom pair and shared by the edges i->j
+ * and j->i; needs a symmetric graph, F <= 128 and TI_PREC_F32 / TI_PREC_F16X2, otherwise the request falls back to
+ * TI_TEMPLATE_THROUGHPUT; the divergence / tangent entry points always use a directed layout).  Results are bit-identical
+ * within one layout and agree to fp32 round-off across them, so a run sharded over ranks pins the layout it would use for the
+ * GLOBAL batch and becomes independent of the rank count.  (The TI_TEMPLATE environment variable, read per call, overrides this.) */
+enum { TI_TEMPLATE_AUTO = -1, TI_TEMPLATE_THROUGHPUT = 0, TI_TEMPLATE_LATENCY = 1, TI_TEMPLATE_PAIR = 2 };
 int ti_painn_set_template(ti_handle* h, int which);
-/* the layout ti_painn_* would choose for a batch of B molecules (TI_TEMPLATE_THROUGHPUT / _LATENCY) */
+/* the layout ti_painn_drift / ti_painn_rollout would choose for a batch of B molecules (TI_TEMPLATE_THROUGHPUT / _LATENCY / _PAIR) */
 int ti_painn_template_for(ti_handle* h, int64_t B);
 /* Pre-size the HBM workspace for batches up to B trajectories (otherwise grown on demand). */
 int ti_reserve(ti_handle* h, int64_t B);
@@ -204,8 +215,9 @@ int ti_profile_read(ti_handle* h, int kernel, int64_t* n_launches, double* total
  * 3, 4, 5 = the tangents of s, v, e of the last ti_painn_drift_jvp call, same shapes. */
 int ti_painn_debug_tap(ti_handle* h, int stop_after_stage);   /* stage = 0 embed, 1+2l message l, 2+2l update l; -1 = off */
 int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats);
-/* Device self-test of the MFMA operand/accumulator lane maps the kernels rely on, and of the fp32 -> (hi, lo) fp16 operand split
- * (its 8-instruction form against the plain arithmetic, bit for bit). */
+/* Device self-test of the MFMA operand/accumulator lane maps the kernels rely on, of both fp32 -> (hi, lo) fp16 operand splits
+ * (the 8-instruction forms of formats (a) and (b) against the plain arithmetic, bit for bit, fp16-subnormal residuals included),
+ * and of the fp16 matrix instruction keeping subnormal inputs. */
 int ti_selftest(int device);
 
 #ifdef __cplusplus

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert sorted(ti._lib.ABI_SYMBOLS) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ti_version() == 3          # TI_ABI_VERSION 3: step_offset, ti_wait_stream, ti_set_stream(mode), template pin
+    assert lib.ti_version() == 4          # TI_ABI_VERSION 4: v3 (step_offset, ti_wait_stream, ti_set_stream(mode), template pin) + TI_TEMPLATE_PAIR
 
 
 def test_rollout_rows_matches_oracle_definition(lib):

@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libti_hip.so")
 SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_nb2.hip", "painn_edge_nb4.hip", "painn_edge_nb8.hip",
-           "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
-HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", "painn_edge_kernel.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
+           "painn_pair_nb1.hip", "painn_pair_nb2.hip", "painn_pair_nb4.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
+HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", "painn_edge_kernel.hpp", "painn_pair_kernel.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

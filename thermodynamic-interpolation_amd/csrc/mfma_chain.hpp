@@ -860,6 +860,40 @@ template <int NBK>
 __device__ __forceinline__ void gemm_bt(f32x4& acc0, f32x4& acc1, const Opnd1<NBK>& in, const f32x4* wl4, int lane) { gemm_split_chunk1<NBK, false>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
 template <int NBK>
 __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const Opnd1<NBK>& in, const f32x4* wl4, int lane) { gemm_split_chunk1<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
+// Two operand sets against ONE weight chunk (pair-major message kernel, painn_pair_kernel.hpp: the two directions of 16 atom pairs):
+// every (hi, lo) fragment pair is read from LDS once and feeds six products, three per operand set -- half the LDS fragment
+// reads, weight DMA and barriers per row of the one-set form, and two independent accumulator chains per output block.
+template <int NBK, bool FLIP>
+__device__ __forceinline__ void gemm_split_chunk1_x2(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const Opnd1<NBK>& inA, const Opnd1<NBK>& inB,
+                                                     const h8* wl, int lane)
+{
+    constexpr int KS = NBK / 2, STEPS = 2 * KS, AH = TI_FRAG_AHEAD < STEPS ? TI_FRAG_AHEAD : STEPS;
+    h8 fh[AH + 1], fl[AH + 1];
+#pragma unroll
+    for (int s = 0; s < AH; ++s) { fh[s] = wl[(2 * s) * 64 + lane]; fl[s] = wl[(2 * s + 1) * 64 + lane]; }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + AH < STEPS) {
+            fh[(s + AH) % (AH + 1)] = wl[(2 * (s + AH)) * 64 + lane];
+            fl[(s + AH) % (AH + 1)] = wl[(2 * (s + AH) + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0x16);
+        const h8 wh = fh[s % (AH + 1)], wlo = fl[s % (AH + 1)];
+        const int m = s % KS;
+        f32x4& accA = s < KS ? a0 : a1;
+        f32x4& accB = s < KS ? b0 : b1;
+        if (FLIP) {
+            accA = mfma16h(inA.hi[m], wh, accA); accB = mfma16h(inB.hi[m], wh, accB);
+            accA = mfma16h(inA.lo[m], wh, accA); accB = mfma16h(inB.lo[m], wh, accB);
+            accA = mfma16h(inA.hi[m], wlo, accA); accB = mfma16h(inB.hi[m], wlo, accB);
+        } else {
+            accA = mfma16h(wh, inA.hi[m], accA); accB = mfma16h(wh, inB.hi[m], accB);
+            accA = mfma16h(wh, inA.lo[m], accA); accB = mfma16h(wh, inB.lo[m], accB);
+            accA = mfma16h(wlo, inA.hi[m], accA); accB = mfma16h(wlo, inB.hi[m], accB);
+        }
+        __builtin_amdgcn_sched_barrier(0x16);
+    }
+}
 // ---------------------------------------------------------------------------------------------------------------------
 // fp16-storage mode (include/ti_hip.h TI_PREC_F16; BASELINE.json configs[4] "fp16 node features with MFMA linears"): the state
 // tensors s, v, P, e live in HBM as fp16, every matrix product is ONE v_mfma_f32_16x16x32_f16 per 32-wide k-step on the fp16
@@ -1109,6 +1143,54 @@ __device__ __forceinline__ void gemm_fl2(f32x4& a0, f32x4& a1, f32x4& t0, f32x4&
     const h8* wl = reinterpret_cast<const h8*>(wl4);
     gemm_pair_split_block<NBK, true>(a0, t0, in, tin, wl, lane);
     gemm_pair_split_block<NBK, true>(a1, t1, in, tin, wl + NBK * 64, lane);
+}
+
+// ---- two operand sets (the two directions of a pair block) against the pipe's current chunk, every matrix path
+template <int NBK, bool FLIP>
+__device__ __forceinline__ void gemm_half_chunk_x2(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const OpndH<NBK>& inA, const OpndH<NBK>& inB,
+                                                   const h8* wl, int lane)
+{
+    constexpr int KS = NBK / 2, STEPS = 2 * KS;
+    h8 f[2];
+    f[0] = wl[lane];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + 1 < STEPS) f[(s + 1) & 1] = wl[(s + 1) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0x16);
+        const int m = s % KS;
+        f32x4& accA = s < KS ? a0 : a1;
+        f32x4& accB = s < KS ? b0 : b1;
+        if (FLIP) { accA = mfma16h(inA.hi[m], f[s & 1], accA); accB = mfma16h(inB.hi[m], f[s & 1], accB); }
+        else      { accA = mfma16h(f[s & 1], inA.hi[m], accA); accB = mfma16h(f[s & 1], inB.hi[m], accB); }
+        __builtin_amdgcn_sched_barrier(0x16);
+    }
+}
+template <bool FLIP, int NBK>
+__device__ __forceinline__ void gemm_x2(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const Opnd1<NBK>& inA, const Opnd1<NBK>& inB, const f32x4* wl, int lane)
+{
+    gemm_split_chunk1_x2<NBK, FLIP>(a0, a1, b0, b1, inA, inB, reinterpret_cast<const h8*>(wl), lane);
+}
+template <bool FLIP, int NBK>
+__device__ __forceinline__ void gemm_x2(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const Opnd<NBK, false>& inA, const Opnd<NBK, false>& inB, const f32x4* wl, int lane)
+{
+    gemm_pair_f32<NBK, FLIP>(a0, a1, b0, b1, inA.a, inB.a, wl, lane);
+}
+template <bool FLIP, int NBK>
+__device__ __forceinline__ void gemm_x2(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const Opnd<NBK, true>& inA, const Opnd<NBK, true>& inB, const f32x4* wl4, int lane)
+{
+    const h8* wl = reinterpret_cast<const h8*>(wl4);
+    gemm_pair_split_block<NBK, FLIP>(a0, b0, inA, inB, wl, lane);
+    gemm_pair_split_block<NBK, FLIP>(a1, b1, inA, inB, wl + NBK * 64, lane);
+}
+template <bool FLIP, int NBK>
+__device__ __forceinline__ void gemm_x2(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const OpndH<NBK>& inA, const OpndH<NBK>& inB, const f32x4* wl, int lane)
+{
+    gemm_half_chunk_x2<NBK, FLIP>(a0, a1, b0, b1, inA, inB, reinterpret_cast<const h8*>(wl), lane);
+}
+template <bool FLIP, class OP, class PIPE>
+__device__ __forceinline__ void gemm_x2_on_pipe(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const OP& inA, const OP& inB, PIPE& pipe, int lane)
+{
+    gemm_x2<FLIP>(a0, a1, b0, b1, inA, inB, pipe.acquire(), lane);
 }
 
 }  // namespace r16

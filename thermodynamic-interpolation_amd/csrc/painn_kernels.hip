@@ -22,6 +22,9 @@ namespace ti {
 hipError_t configure_edge_nb1(); hipError_t configure_edge_nb2(); hipError_t configure_edge_nb4(); hipError_t configure_edge_nb8();
 hipError_t launch_edge_nb1(bool, bool, int, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb2(bool, bool, int, const EdgeParams&, hipStream_t);
 hipError_t launch_edge_nb4(bool, bool, int, const EdgeParams&, hipStream_t); hipError_t launch_edge_nb8(bool, bool, int, const EdgeParams&, hipStream_t);
+hipError_t configure_pair_nb1(); hipError_t configure_pair_nb2(); hipError_t configure_pair_nb4();
+hipError_t launch_pair_nb1(bool, bool, int, const EdgeParams&, hipStream_t); hipError_t launch_pair_nb2(bool, bool, int, const EdgeParams&, hipStream_t);
+hipError_t launch_pair_nb4(bool, bool, int, const EdgeParams&, hipStream_t);
 
 // ================================================================================================== update kernel
 // v <- v + dv  with  dv = dvacc + cacc x v   (the cross product with v[dst] factors out of the edge sum),
@@ -450,6 +453,7 @@ static hipError_t configure_nb()
         if ((e = set_lds(painn_readout16_kernel<2 * NB, 2>, n2)) != hipSuccess) return e;
     }
     if ((e = (NB == 1 ? configure_edge_nb1() : NB == 2 ? configure_edge_nb2() : NB == 4 ? configure_edge_nb4() : configure_edge_nb8())) != hipSuccess) return e;
+    if ((e = (NB == 1 ? configure_pair_nb1() : NB == 2 ? configure_pair_nb2() : NB == 4 ? configure_pair_nb4() : hipSuccess)) != hipSuccess) return e;
     const size_t bu = update_lds_bytes(NB, false), bh = update_lds_bytes(NB, true);
     if ((e = set_lds(painn_update_kernel<2 * NB, true, 0>, bu)) != hipSuccess) return e;
     if ((e = set_lds(painn_update_kernel<2 * NB, false, 0>, bu)) != hipSuccess) return e;
@@ -518,6 +522,17 @@ hipError_t launch_edge(int NBv, bool first, bool last, int prec, const EdgeParam
         default: return hipErrorInvalidValue;
     }
 }
+
+hipError_t launch_pair(int NBv, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st)
+{
+    switch (NBv) {
+        case 1: return launch_pair_nb1(first, last, prec, p, st);
+        case 2: return launch_pair_nb2(first, last, prec, p, st);
+        case 4: return launch_pair_nb4(first, last, prec, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+bool pair_kernel_exists(int NB, int prec) { return NB <= 4 && (prec == TI_PREC_F32 || prec == TI_PREC_F16X2); }
 
 hipError_t launch_update(int NBv, bool has_next, int prec, const UpdateParams& p, hipStream_t st)
 {

@@ -3,6 +3,7 @@
 //
 // There is deliberately no CPU fallback in this file: every entry point either runs the HIP kernels or fails.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <stdexcept>
 #include <utility>
 
+#include "pair_template.hpp"
 #include "ti_internal.hpp"
 
 namespace ti {
@@ -159,7 +161,11 @@ struct ti_handle {
         std::vector<int> part_of, part_start, part_len;     // per sorted edge: its part; per part: first sorted edge, edges
         std::vector<int> pos;                     // row of (molecule-in-group m, sorted edge k) inside its part: pos[m * part_len + (k - part_start)]
         int max_slots = 0;                        // most destination atoms in any row block (<= EDGE_MAX_SLOTS)
-    } tpl[2];
+    } tpl[3];
+    // tpl[2]: the pair-major template (ti_internal.hpp; painn_pair_kernel.hpp), built when the graph is symmetric and the pair kernel
+    // exists for this width / precision.  pair_pos[(m * A + src) * A + dst] = e row of that directed edge of molecule-in-group m inside
+    // its group: (block * 2 + direction) * 16 + pair row
+    bool has_pair = false; std::vector<int> pair_pos; double pair_fill = 0.0;
     int n_tpl = 1, active = 0, parts = 1, max_slots = 0, pinned_tpl = TI_TEMPLATE_AUTO;
     // every atom has incoming edges: the edge kernels' first touch of an accumulator replaces its contents (ti_internal.hpp
     // SLOT_FIRST_TOUCH) and nothing zeroes the accumulators between layers or calls; otherwise the update kernel zeroes them as before
@@ -167,6 +173,7 @@ struct ti_handle {
     struct { const uint32_t* p = nullptr; } rows; struct { const int32_t* p = nullptr; } slotnode;
     DevBuf<int32_t> atom_ids;
     std::vector<int> perm;        // sorted row -> original edge index
+    std::vector<int32_t> esrc, edst;       // the molecule's directed edges as passed to create
     DevBuf<float> x, cond, s, P, v, dsacc, dvacc, cacc, e, enc, geo, b1, b2, xt, edge_vecs, edge_vecs1, upd_vecs;
     std::vector<float> edge_scale;               // [L][6] per-matrix powers of two of the one-accumulator message streams (TI_PREC_F16X2)
     int tap = -1; long long last_B = 0;
@@ -339,25 +346,49 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
             h->n_tpl = 2;
         }
     }
+    h->esrc.assign(src, src + E); h->edst.assign(dst, dst + E);
+}
+
+
+// ---- pair-major template: pair_template.hpp builds it (pure host code, unit-tested on the CPU); this uploads it
+static bool build_pair_template(ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype)
+{
+    ti::PairTemplate pt;
+    if (!ti::build_pair_template(h->d.n_atoms, h->d.n_edges, src, dst, etype, h->first_touch, pt)) return false;
+    ti_handle::Tpl& T = h->tpl[2];
+    T.G = pt.G; T.P = 1; T.nblk = pt.nblk; T.max_slots = 4;
+    T.rows.upload(pt.rows); T.slotnode.upload(pt.slotnode);
+    h->pair_pos = pt.pair_pos; h->pair_fill = pt.fill;
+    return true;
 }
 
 // Template for a call over B molecules: the latency template while the throughput one would leave SIMDs without a wave
 // (fewer groups than the 1024 SIMDs of the chip); TI_TEMPLATE=throughput|latency pins it (tests, reproducibility across shards).
-int template_for(const ti_handle* h, long long B)
+int template_for(const ti_handle* h, long long B, bool allow_pair = true)
 {
-    int pick = 0;
-    if (h->n_tpl > 1) {
-        const long long groups0 = (B + h->tpl[0].G - 1) / h->tpl[0].G;
-        pick = groups0 < 1024 ? 1 : 0;
-        if (h->pinned_tpl != TI_TEMPLATE_AUTO) pick = h->pinned_tpl;
-        if (const char* e = std::getenv("TI_TEMPLATE")) pick = std::strcmp(e, "latency") == 0 ? 1 : std::strcmp(e, "throughput") == 0 ? 0 : pick;
+    int dir_pick = 0;                        // among the directed layouts: latency while the throughput one would leave SIMDs idle
+    if (h->n_tpl > 1) dir_pick = (B + h->tpl[0].G - 1) / h->tpl[0].G < 1024 ? 1 : 0;
+    const bool pair_ok = h->has_pair && allow_pair;
+    // pair-major rows once they fill the chip (one wave per group of G molecules) and cost less than the directed rows: a pair block
+    // runs 84 chunk products for 16 pairs where a directed block runs 56 for 16 edges, at half the weight-chunk visits per edge
+    int pick = dir_pick;
+    if (pair_ok) {
+        const ti_handle::Tpl &T = h->tpl[2], &D = h->tpl[0];
+        if ((B + T.G - 1) / T.G >= 1024 && 1.5 * T.nblk / T.G <= (double)D.nblk / D.G) pick = 2;
     }
+    int want = h->pinned_tpl;
+    if (const char* e = std::getenv("TI_TEMPLATE"))
+        want = std::strcmp(e, "latency") == 0 ? 1 : std::strcmp(e, "throughput") == 0 ? 0 : std::strcmp(e, "pair") == 0 ? 2 : want;
+    if (want == TI_TEMPLATE_THROUGHPUT) pick = 0;
+    else if (want == TI_TEMPLATE_LATENCY) pick = h->n_tpl > 1 ? 1 : 0;
+    else if (want == TI_TEMPLATE_PAIR) pick = pair_ok ? 2 : dir_pick;
     return pick;
 }
 
-void select_template(ti_handle* h, long long B)
+// allow_pair = false: the divergence / tangent entry points (their kernels walk directed rows)
+void select_template(ti_handle* h, long long B, bool allow_pair = true)
 {
-    const int pick = template_for(h, B);
+    const int pick = template_for(h, B, allow_pair);
     const ti_handle::Tpl& T = h->tpl[pick];
     h->active = pick; h->G = T.G; h->parts = T.P; h->nblk = T.nblk; h->rows.p = T.rows.p; h->slotnode.p = T.slotnode.p;
     h->max_slots = T.max_slots;
@@ -367,6 +398,10 @@ void select_template(ti_handle* h, long long B)
 size_t edge_row_of(const ti_handle* h, size_t m, size_t k)
 {
     const ti_handle::Tpl& T = h->tpl[h->active];
+    if (h->active == 2) {                   // pair-major rows: [group][block][direction][16]
+        const size_t A = h->d.n_atoms;
+        return (m / T.G) * (size_t)T.nblk * 2 * ti::EDGE_ROWS_PER_BLOCK + (size_t)h->pair_pos[((m % T.G) * A + h->esrc[h->perm[k]]) * A + h->edst[h->perm[k]]];
+    }
     // throughput template: one part, pos over (molecule in group, sorted edge); latency template: G = 1, pos over the sorted edge
     const size_t part = T.part_of[k], r = T.pos[(m % T.G) * (size_t)h->d.n_edges + k];
     return ((m / T.G) * T.P + part) * T.nblk * ti::EDGE_ROWS_PER_BLOCK + r;
@@ -380,6 +415,8 @@ size_t edge_rows_for(const ti_handle* h, long long B, long long copies = 1)
         const ti_handle::Tpl& T = h->tpl[t];
         best = std::max<size_t>(best, (size_t)((B + T.G - 1) / T.G) * (size_t)copies * T.P * T.nblk * ti::EDGE_ROWS_PER_BLOCK);
     }
+    if (h->has_pair && copies == 1)         // two directions per pair row
+        best = std::max<size_t>(best, (size_t)((B + h->tpl[2].G - 1) / h->tpl[2].G) * h->tpl[2].nblk * 2 * ti::EDGE_ROWS_PER_BLOCK);
     return best;
 }
 
@@ -606,6 +643,7 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
     const bool split = h->d.precision == TI_PREC_F16X2;
     const int prec = h->d.precision;
     if (jr && prec == TI_PREC_F16) throw std::invalid_argument("the fp16 storage mode has no divergence / tangent path (use f32 or f16x2)");
+    if (jr && h->active == 2) throw std::logic_error("tangent passes walk directed edge rows (select_template(.., allow_pair = false))");
     const long long VB = jr ? jvp_virtual_molecules(h, B, jr->D) : 0, VN = VB * A, vgroups = VB / h->G * h->parts;
     if (jr) {
         ensure_jvp_ws(h, B, jr->D);
@@ -675,7 +713,8 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
                 for (int i = 0; i < 6; ++i) p.wscale[i] = h->edge_scale[(size_t)l * 6 + i];
             }
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
-            HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
+            if (h->active == 2) HIP_CHECK(launch_pair(NB, l == 0, l == L - 1, prec, p, st));
+            else HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
         }
         if (h->tap == 1 + 2 * l) return;
         if (jr) {
@@ -1122,6 +1161,7 @@ ti_handle* ti_painn_create(const ti_painn_desc* d, const float* weights, size_t 
         h->flat.upload(flat);
         h->atom_ids.upload(std::vector<int32_t>(atom_ids, atom_ids + A));
         build_templates(h.get(), edge_src, edge_dst, edge_type);
+        h->has_pair = pair_kernel_exists(h->NB, d->precision) && build_pair_template(h.get(), edge_src, edge_dst, edge_type);
         select_template(h.get(), 1 << 20);
         pack_painn(h.get(), weights);
         HIP_CHECK(configure_painn_kernels(h->NB));
@@ -1196,7 +1236,7 @@ int ti_painn_drift_jvp(ti_handle* h, const float* x, const float* xdot, float t,
     if (B == 0) return TI_OK;
     return guarded([&]() -> int {
         set_device(h);
-        select_template(h, B);
+        select_template(h, B, false);
         ensure_painn_ws(h, B);
         ensure_jvp_ws(h, B, 1);
         const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
@@ -1227,7 +1267,7 @@ int ti_painn_drift_div(ti_handle* h, const float* x, float t, const float* cond,
     if (h->tap >= 0) return fail(TI_E_ARG, "debug taps apply to ti_painn_drift / ti_painn_drift_jvp only");
     return guarded([&]() -> int {
         set_device(h);
-        select_template(h, B);
+        select_template(h, B, false);
         ensure_painn_ws(h, B);
         const size_t n = (size_t)B * h->d.n_atoms * 3, nc = (size_t)B * h->d.n_atoms * h->ncond;
         const float *xd = x, *cd = cond; float *od = out, *dd = out_div;
@@ -1257,7 +1297,7 @@ int ti_painn_rollout_dlogp(ti_handle* h, const ti_rollout_desc* rd, const float*
     if (B == 0) { if (n_fevals) *n_fevals = 0; return TI_OK; }
     return guarded([&]() -> int {
         set_device(h);
-        select_template(h, B);
+        select_template(h, B, false);
         ensure_painn_ws(h, B);
         const int A = h->d.n_atoms;
         const size_t n = (size_t)B * A * 3, nc = (size_t)B * A * h->ncond;
@@ -1320,7 +1360,7 @@ int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)
                     }
         } else if (what == 2) {
             if (n_floats != B * E * F) return fail(TI_E_ARG, "size mismatch (e)");
-            const size_t RB = ti::EDGE_ROWS_PER_BLOCK, rows = (B + h->G - 1) / h->G * h->parts * h->nblk * RB;
+            const size_t RB = ti::EDGE_ROWS_PER_BLOCK, rows = (B + h->G - 1) / h->G * h->parts * h->nblk * RB * (h->active == 2 ? 2 : 1);
             std::vector<float> e(rows * F);
             HIP_CHECK(hipMemcpy(e.data(), h->e.p, e.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (size_t m = 0; m < B; ++m)
@@ -1517,8 +1557,9 @@ int ti_wait_stream(ti_handle* h, void* producer_stream)
 int ti_painn_set_template(ti_handle* h, int which)
 {
     if (!h || h->kind != 0) return fail(TI_E_ARG, "not a painn handle");
-    if (which != TI_TEMPLATE_AUTO && which != TI_TEMPLATE_THROUGHPUT && which != TI_TEMPLATE_LATENCY) return fail(TI_E_ARG, "unknown template");
+    if (which != TI_TEMPLATE_AUTO && which != TI_TEMPLATE_THROUGHPUT && which != TI_TEMPLATE_LATENCY && which != TI_TEMPLATE_PAIR) return fail(TI_E_ARG, "unknown template");
     if (which == TI_TEMPLATE_LATENCY && h->n_tpl < 2) which = TI_TEMPLATE_THROUGHPUT;      // this species has only one layout
+    if (which == TI_TEMPLATE_PAIR && !h->has_pair) which = TI_TEMPLATE_THROUGHPUT;         // no pair-major layout for this graph / width / precision
     h->pinned_tpl = which;
     return TI_OK;
 }

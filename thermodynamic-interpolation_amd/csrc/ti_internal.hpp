@@ -37,6 +37,23 @@ __host__ __device__ inline int row_dst(uint32_t w) { return (w >> 11) & 31; }
 __host__ __device__ inline int row_type(uint32_t w) { return (w >> 16) & 3; }
 __host__ __device__ inline int row_slot(uint32_t w) { return (w >> 18) & 63; }
 
+// ---- pair-major template (painn_pair_kernel.hpp; ti_api.hip: build_pair_template).  The filter branch w(enc(|r_ij|)) of SE3Message
+// (cpainn.py:283-289) depends on the edge length only, so the edges i->j and j->i share it bit for bit.  A row block holds 16 atom PAIRS
+// laid out as a 4 x 4 tile: row 4a + b = pair (I[a], J[b]) of up to four "I" atoms and four "J" atoms (slots carry molecule-in-group and
+// atom; rows of pairs that do not exist are invalid).  Direction A is the edge I[a] -> J[b] (src I, dst J), direction B the edge
+// J[b] -> I[a].  The per-atom sums need no masks: direction B's destination is the same for the four rows a lane holds (in-lane adds),
+// direction A's is the same across the four lane rows (two lane-swap levels).
+//   row word : bit0 valid | molI<<1 (3b) | atomI<<4 (5b) | molJ<<9 (3b) | atomJ<<12 (5b) | etype<<17 (2b)     (empty slots: a safe atom)
+//   slot word: slotnode[blk*16 + k], k = 0..3 the I slots, k = 4..7 the J slots: -1, or atom | mol<<8 | SLOT_FIRST_TOUCH
+// Within a block, for any accumulator element, direction A's contribution is issued before direction B's (first-touch order).
+// e rows: [group][block][direction][16][F]; the parked encoding / edge_dir (direction A's) once per pair: [group][block][16].
+constexpr int PAIR_MAX_G = 8;
+__host__ __device__ inline int prow_molI(uint32_t w) { return (w >> 1) & 7; }
+__host__ __device__ inline int prow_atomI(uint32_t w) { return (w >> 4) & 31; }
+__host__ __device__ inline int prow_molJ(uint32_t w) { return (w >> 9) & 7; }
+__host__ __device__ inline int prow_atomJ(uint32_t w) { return (w >> 12) & 31; }
+__host__ __device__ inline int prow_type(uint32_t w) { return (w >> 17) & 3; }
+
 struct MlpVec {           // natural-order per-feature vectors of one reference MLP block (device pointers)
     const float *b0, *g0, *be0, *b1, *g1, *be1, *b2;
 };
@@ -92,6 +109,9 @@ struct ReadoutParams {
 hipError_t launch_embed(int NB, int nseg, int prec, const EmbedParams& p, hipStream_t st);
 hipError_t launch_edge(int NB, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st);
 bool edge_uses_one_chain(int NB, int prec);      // message kernel on the one-accumulator split format (painn_edge_kernel.hpp: edge_one_chain)
+// pair-major message kernel (painn_pair_kernel.hpp): same EdgeParams, rows / slotnode of the pair template, same weight stream
+hipError_t launch_pair(int NB, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st);
+bool pair_kernel_exists(int NB, int prec);
 hipError_t launch_update(int NB, bool has_next, int prec, const UpdateParams& p, hipStream_t st);
 hipError_t launch_readout(int NB, int prec, const ReadoutParams& p, hipStream_t st);
 hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes

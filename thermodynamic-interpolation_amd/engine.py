@@ -139,15 +139,16 @@ class PainnEngine(_Engine):
         if not self.h:
             raise _lib.TiError(-1, _lib.last_error())
 
-    TEMPLATES = {"auto": -1, "throughput": 0, "latency": 1}
+    TEMPLATES = {"auto": -1, "throughput": 0, "latency": 1, "pair": 2}
 
     def set_template(self, which: str = "auto"):
-        """Pin the edge-row layout ('throughput' | 'latency') or let each call choose from its batch size ('auto')."""
+        """Pin the edge-row layout ('throughput' | 'latency': directed rows; 'pair': pair-major rows, the filter branch once per atom
+        pair -- falls back to 'throughput' where no pair layout exists) or let each call choose from its batch size ('auto')."""
         _lib.check(_lib.lib().ti_painn_set_template(self.h, self.TEMPLATES[which]))
 
     def template_for(self, B: int) -> str:
-        """The layout a call over B molecules would use."""
-        return "latency" if _lib.lib().ti_painn_template_for(self.h, int(B)) == 1 else "throughput"
+        """The layout a drift / rollout call over B molecules would use."""
+        return {0: "throughput", 1: "latency", 2: "pair"}[_lib.lib().ti_painn_template_for(self.h, int(B))]
 
     def _check_x(self, x, name="x"):
         if x is None or len(x.shape) != 3 or tuple(x.shape[1:]) != (self.A, 3):

@@ -6,7 +6,8 @@
 
 FLAGS are extra hipcc flags, '+'-separated (e.g. nopk:-Xclang+-target-feature+-Xclang+-packed-fp32-ops, x:-DTI_SOMETHING=1);
 ONLY=file.hip restricts recompilation to that source (the product objects of the others are linked).
-TAG `base` means the product library.  `run` starts one child process per (round, tag), interleaved, so that clock and box
+TAG `base` means the product library; `TAG@LAYOUT` (run only) pins the edge-row layout of that arm (throughput | latency | pair;
+default: TI_VB_TEMPLATE or throughput), e.g. `base@throughput base@pair`.  `run` starts one child process per (round, tag), interleaved, so that clock and box
 drift hit every variant alike; each child reports the HIP-event averages of the edge and update kernels, the wall time per
 step, and the drift of 64 molecules, which is compared with the first tag's (max abs difference) and with the f32 path's.
 No torch import anywhere (a fresh box pays 1-2 minutes for it)."""
@@ -21,10 +22,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "thermodynamic-interpolation_amd")
 VDIR = os.path.join(PKG, "build", "variants")
 SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_nb2.hip", "painn_edge_nb4.hip", "painn_edge_nb8.hip",
-           "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
+           "painn_pair_nb1.hip", "painn_pair_nb2.hip", "painn_pair_nb4.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
 
 
 def lib_of(tag):
+    tag = tag.partition("@")[0]
     return os.path.join(PKG, "libti_hip.so") if tag == "base" else os.path.join(VDIR, f"libti_hip_{tag}.so")
 
 
@@ -95,6 +97,8 @@ def run(argv):
 
     def spawn(tag, precision, small):
         env = dict(os.environ, TI_LIB_PATH=lib_of(tag))
+        if "@" in tag:
+            env["TI_VB_TEMPLATE"] = tag.partition("@")[2]
         cmd = [sys.executable, os.path.abspath(__file__), "child", str(a.batch), str(a.steps), precision, "1" if small else "0"]
         try:
             p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
