@@ -141,10 +141,15 @@ def build_model(variant, F, L, temp_length, temperatures, sd):
 
 
 def run_with_intermediates(model, batch):
-    """Forward through the reference nn.Sequential, recording s/v/e after every PaiNNBase sub-layer."""
+    """Forward through the reference nn.Sequential, recording s/v/e after every PaiNNBase sub-layer, and the largest |value| any
+    hidden activation (a SiLU output inside an MLP of a message / update block: what the next Linear multiplies) takes per MLP."""
     rec = {}
     mods = list(model.net)
     b = batch
+    hid, hooks = {}, []
+    for name, mod in mods[-1].layers.named_modules():
+        if isinstance(mod, torch.nn.SiLU) and int(name.split(".")[0]) < len(mods[-1].layers) - 1:      # (the last layer is the readout)
+            hooks.append(mod.register_forward_hook(lambda m, i, o, k=name: hid.__setitem__(k, max(hid.get(k, 0.0), float(o.abs().max())))))
     with torch.no_grad():
         for m in mods[:-1]:
             b = m(b)
@@ -161,6 +166,11 @@ def run_with_intermediates(model, batch):
                 rec[f"e_{tag}"] = b.invariant_edge_features.numpy().copy()
         b = layers[-1](b)
         rec["out"] = b.equivariant_node_features.squeeze().numpy().copy()
+    for h in hooks:
+        h.remove()
+    keys = sorted(hid)
+    rec["hidden_names"] = np.asarray(keys)
+    rec["hidden_absmax"] = np.asarray([hid[k] for k in keys], np.float64)
     return rec
 
 
@@ -370,12 +380,42 @@ def range_cases():
                recipe=[(k.replace("net.7.", "net.6."), f) for k, f in big])
 
 
+def lnaff_cases():
+    """LayerNorm affines of the message / update MLPs (embedding.py:27-35: Linear -> LayerNorm -> SiLU chain) rescaled, so that the
+    hidden activations -- the operands of the next matrix product -- are 1e-5 (below fp16's smallest normal 6.1e-5), 1e-3 or 1e3
+    times their usual O(1) size (the unscaled activation split of the one-accumulator format resolves 2^-24
+    absolutely).  `harsh` also shrinks the bias of the Linear that follows, so that W h is not swamped by it and the second LayerNorm
+    really amplifies what the product lost.  hidden_absmax is recorded so the test can assert the magnitudes were reached."""
+    fc = syn.fully_connected_template
+
+    def recipe(f, L, harsh=False, which=(1, 4)):
+        r = []
+        for blk in ("phi", "w"):
+            r += [(f"{blk}.mlp.{i}.{wb}", f) for i in which for wb in ("weight", "bias")]
+            if harsh:
+                r += [(f"{blk}.mlp.3.bias", f)]
+        for l in range(L):
+            r += [(f"layers.{2 * l + 1}.mlp.mlp.{i}.{wb}", f) for i in which for wb in ("weight", "bias")]
+            if harsh:
+                r += [(f"layers.{2 * l + 1}.mlp.mlp.3.bias", f)]
+        return r
+    for tag, f, which in (("1em5", 1e-5, (1, 4)), ("1em3", 1e-3, (1, 4)), ("1e3", 1e3, (1,))):
+        # (1e3 on the FIRST LayerNorm of each MLP only: on both, the reference itself overflows to NaN within two layers)
+        painn_case(f"lnaff_{tag}_f32", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=31, intermediates=True, recipe=recipe(f, 2, which=which))
+        painn_case(f"lnaff_{tag}_f128", W.AMBIENT, 128, 2, 5, 2, fc(5), 100, TEMPS, seed=32, intermediates=True, recipe=recipe(f, 2, which=which))
+    painn_case("lnaff_harsh_f32", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=33, intermediates=True, recipe=recipe(1e-5, 2, True))
+    painn_case("lnaff_harsh_f128", W.AMBIENT, 128, 2, 5, 2, fc(5), 100, TEMPS, seed=34, intermediates=True, recipe=recipe(1e-5, 2, True))
+
+
 TEMPS = [300, 400, 500, 600, 700, 800, 900, 1000]
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if "--range-only" in sys.argv:    # only the magnitude edge cases (the other fixtures are unchanged by them)
         range_cases()
+        sys.exit(0)
+    if "--lnaff-only" in sys.argv:    # only the LayerNorm-affine cases
+        lnaff_cases()
         sys.exit(0)
     if "--div-only" in sys.argv:      # only the divergence fixtures (the drift fixtures above are unchanged by them)
         div_cases()
@@ -403,3 +443,4 @@ if __name__ == "__main__":
     adw_case("adw_ctor_h64", 64, 3, 16, seed=1, ctor_init=True)
     div_cases()
     range_cases()
+    lnaff_cases()

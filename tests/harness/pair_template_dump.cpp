@@ -1,7 +1,7 @@
 // pair_template_dump.cpp -- test harness (tests/test_pair_template.py): reads one molecule's directed edge list from stdin
-// ("A E first_touch" then E lines "src dst type"), runs the product's pair-template builder (csrc/pair_template.hpp, the code
-// libti_hip.so uses) and prints the template as plain integers:  "ok G nblk" | "none", then nblk*16 row words, nblk*16 slot words,
-// G*A*A pair_pos entries.
+// ("A E" then E lines "src dst type"), runs the product's pair-template builder (csrc/pair_template.hpp, the code
+// libti_hip.so uses) and prints the template as plain integers:  "ok G nblk kmax" | "none", then nblk*16 row words, nblk*16 slot
+// words, G*A*A pair_pos entries, G*A*kmax partial-list entries.
 #include <cstdio>
 #include <vector>
 
@@ -9,18 +9,20 @@
 
 int main()
 {
-    int A, E, ft;
-    if (std::scanf("%d %d %d", &A, &E, &ft) != 3) return 2;
+    int A, E;
+    if (std::scanf("%d %d", &A, &E) != 2) return 2;
     std::vector<int32_t> s(E), d(E), t(E);
     for (int k = 0; k < E; ++k) if (std::scanf("%d %d %d", &s[k], &d[k], &t[k]) != 3) return 2;
     ti::PairTemplate pt;
-    if (!ti::build_pair_template(A, E, s.data(), d.data(), t.data(), ft != 0, pt)) { std::printf("none\n"); return 0; }
-    std::printf("ok %d %d\n", pt.G, pt.nblk);
+    if (!ti::build_pair_template(A, E, s.data(), d.data(), t.data(), pt)) { std::printf("none\n"); return 0; }
+    std::printf("ok %d %d %d\n", pt.G, pt.nblk, pt.kmax);
     for (uint32_t w : pt.rows) std::printf("%u ", w);
     std::printf("\n");
     for (int32_t w : pt.slotnode) std::printf("%d ", w);
     std::printf("\n");
     for (int w : pt.pair_pos) std::printf("%d ", w);
+    std::printf("\n");
+    for (int32_t w : pt.plist) std::printf("%d ", w);
     std::printf("\n");
     return 0;
 }

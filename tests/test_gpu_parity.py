@@ -452,6 +452,46 @@ def test_magnitude_edge_cases_vs_reference(name, precision):
         assert err < max(DRIFT_TOL, 3 * floor), (name, precision, i, err, floor)
 
 
+LNAFF_CASES = ["lnaff_1em5_f32", "lnaff_1em5_f128", "lnaff_1em3_f32", "lnaff_1em3_f128", "lnaff_1e3_f32", "lnaff_1e3_f128",
+               "lnaff_harsh_f32", "lnaff_harsh_f128"]
+
+
+def check_lnaff_magnitudes(name, g):
+    """The fixture really drives the hidden activations (SiLU outputs inside the message / update MLPs) where it says."""
+    h = g["im::hidden_absmax"]
+    if "1em5" in name or "harsh" in name:
+        assert h.max() < 6.1e-5                             # every hidden row below fp16's smallest normal number
+    elif "1em3" in name:
+        assert 1e-4 < h.max() < 1e-2
+    else:
+        assert h.max() > 2e3
+
+
+@pytest.mark.parametrize("template", ["throughput", "pair"])
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("name", LNAFF_CASES)
+def test_layernorm_affine_magnitudes_vs_reference(name, precision, template):
+    """Reference fixtures whose message / update LayerNorm affines (embedding.py:27-35) are rescaled by 1e-5, 1e-3 and 1e3: the
+    hidden activations -- the operands the split-fp16 path feeds to the next matrix product -- sit in fp16's subnormal range, two
+    binades above it, or at 4e3.  `harsh` also shrinks the next Linear's bias, so nothing swamps what the product loses.  Bar as
+    for the other magnitude cases: max(1e-5, 3 x the reference's own distance to exact arithmetic), both matrix paths, directed
+    and pair-major message kernels."""
+    g = load_golden(name)
+    check_lnaff_magnitudes(name, g)
+    ti = pkg()
+    eng = ti.engine.PainnEngine(int(g["variant"]), int(g["F"]), int(g["L"]), int(g["A"]), g["edge_src"], g["edge_dst"], g["edge_type"],
+                                g["atom_ids"], golden_weights(g), temp_length=float(g["temp_length"]), temperatures=g["temperatures"],
+                                precision=precision)
+    eng.set_template(template)
+    orc = oracle_from_golden(g)
+    for i, t in enumerate(g["ts"]):
+        got = eng.drift(g["x"], float(t), g["cond"])
+        assert np.isfinite(got).all(), (name, precision)
+        err = rel_l2(got, g[f"drift_{i}"])
+        floor = rel_l2(g[f"drift_{i}"], orc.drift(g["x"], float(t), g["cond"], precision=64))
+        assert err < max(DRIFT_TOL, 3 * floor), (name, precision, template, i, err, floor)
+
+
 def test_f16x2_refuses_weights_beyond_the_fp16_range():
     ti = pkg()
     syn, W = ti.synthetic, ti.weights

@@ -8,44 +8,39 @@ import pytest
 
 from conftest import ROOT, pkg
 
-FIRST = 1 << 30
-
 
 @pytest.fixture(scope="module")
 def dump(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("pair") / "pair_template_dump")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "pair_template_dump.cpp")])
 
-    def run(A, src, dst, et, first_touch=True):
-        text = f"{A} {len(src)} {int(first_touch)}\n" + "".join(f"{s} {d} {t}\n" for s, d, t in zip(src, dst, et))
+    def run(A, src, dst, et):
+        text = f"{A} {len(src)}\n" + "".join(f"{s} {d} {t}\n" for s, d, t in zip(src, dst, et))
         out = subprocess.run([exe], input=text, capture_output=True, text=True, check=True).stdout.split("\n")
         if out[0].strip() == "none":
             return None
-        _, G, nblk = out[0].split()
-        G, nblk = int(G), int(nblk)
+        _, G, nblk, kmax = out[0].split()
+        G, nblk, kmax = int(G), int(nblk), int(kmax)
         rows = np.array(out[1].split(), dtype=np.int64).reshape(nblk, 16)
         slots = np.array(out[2].split(), dtype=np.int64).reshape(nblk, 16)
         pos = np.array(out[3].split(), dtype=np.int64).reshape(G, A, A)
-        return G, nblk, rows, slots, pos
+        plist = np.array(out[4].split(), dtype=np.int64).reshape(G, A, kmax)
+        return G, nblk, rows, slots, pos, plist
     return run
 
 
-def check_template(A, src, dst, et, tpl, first_touch=True):
-    G, nblk, rows, slots, pos = tpl
+def check_template(A, src, dst, et, tpl):
+    G, nblk, rows, slots, pos, plist = tpl
     etype = {(s, d): t for s, d, t in zip(src, dst, et)}
-    seen, touched = set(), set()
+    seen, owner = set(), {}
     for b in range(nblk):
         I, J = slots[b, :4], slots[b, 4:8]
         assert np.all(slots[b, 8:] == -1)
         keys = lambda s: [(int(w) >> 8 & 0x3FFFFF, int(w) & 255) for w in s if w >= 0]
-        assert len(set(keys(I))) == len(keys(I)) and len(set(keys(J))) == len(keys(J))      # distinct accumulators inside one atomic instruction
-        # first-touch flags: J slots are issued before I slots
-        for w in list(J) + list(I):
-            if w < 0:
-                continue
-            key = (int(w) >> 8 & 0x3FFFFF, int(w) & 255)
-            assert bool(w & FIRST) == (first_touch and key not in touched)
-            touched.add(key)
+        assert len(set(keys(I))) == len(keys(I)) and len(set(keys(J))) == len(keys(J))      # an atom at most once per side
+        for k in range(8):                                   # partial row (block, slot) -> the atom whose sum it holds
+            if slots[b, k] >= 0:
+                owner[8 * b + k] = (int(slots[b, k]) >> 8 & 0x3FFFFF, int(slots[b, k]) & 255)
         for a in range(4):
             for c in range(4):
                 w = int(rows[b, 4 * a + c])
@@ -62,7 +57,16 @@ def check_template(A, src, dst, et, tpl, first_touch=True):
                         seen.add(e)
                     assert pos[mI, aI, aJ] == (2 * b) * 16 + 4 * a + c and pos[mI, aJ, aI] == (2 * b + 1) * 16 + 4 * a + c
     assert seen == {(m, s, d) for m in range(G) for s, d in zip(src, dst)}            # every directed edge of every molecule exactly once
-    assert touched == {(m, a) for m in range(G) for a in set(dst)}
+    # the partial lists: every occupied (block, slot) appears in exactly one list, its atom's, in walk order
+    listed = {}
+    for m in range(G):
+        for a in range(A):
+            ids = [int(v) for v in plist[m, a] if v >= 0]
+            assert ids == sorted(ids) and list(plist[m, a][:len(ids)]) == ids              # -1 only as padding at the end
+            for i in ids:
+                assert i not in listed
+                listed[i] = (m, a)
+    assert listed == owner
     return sum(int(w) & 1 for w in rows.ravel()) / (nblk * 16.0)
 
 
@@ -92,10 +96,9 @@ def test_sparse_and_asymmetric_graphs(dump):
         src, dst, et = np.concatenate([i, j]), np.concatenate([j, i]), np.concatenate([ty, ty])
         order = np.lexsort((dst, src))
         src, dst, et = src[order], dst[order], et[order]
-        for ft in (True, False):
-            tpl = dump(A, src, dst, et, ft)
-            assert tpl is not None
-            check_template(A, [int(v) for v in src], [int(v) for v in dst], [int(v) for v in et], tpl, ft)
+        tpl = dump(A, src, dst, et)
+        assert tpl is not None
+        check_template(A, [int(v) for v in src], [int(v) for v in dst], [int(v) for v in et], tpl)
     # not the symmetric closure of an undirected graph -> no pair template (the directed kernels serve it)
     assert dump(3, [0, 1, 1], [1, 0, 2], [0, 0, 0]) is None                     # 2 -> 1 missing (odd edge count)
     assert dump(3, [0, 1, 1, 2], [1, 0, 2, 1], [0, 1, 0, 0]) is None            # types differ between the two directions

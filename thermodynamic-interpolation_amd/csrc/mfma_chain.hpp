@@ -172,7 +172,11 @@ struct PipeDMA {
             dma(g + (size_t)next * SUP4, base + (par ^ 1) * SUP4);
         }
         if (++sub == SC) {
+#ifdef TI_EXP_VMCNT       // experiment builds only: an (incorrect) lax wait, to price the in-order vmcnt drain of older atomics
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TI_EXP_VMCNT) : "memory");
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __syncthreads();
             idx = (idx + 1 == nsup) ? 0 : idx + 1;
             par ^= 1; sub = 0;

@@ -26,11 +26,19 @@ struct EV {
 // Fire-and-forget fp32 add (global_atomic_add_f32, no return): nothing waits for the memory round trip.  Every
 // accumulator element starts at zero and is only ever added to by the one wave that owns the molecule, in program
 // order (an atom's <= 31 incoming edges span at most three 16-row blocks of that wave).
+#ifdef TI_EXP_NOATOM      // experiment builds only (tools/variant_bench.py): the accumulator traffic switched off at run time, values kept alive
+static __device__ bool ti_exp_never;      // never set
+__device__ __forceinline__ void add_noret(float* p, float v) { if (ti_exp_never) unsafeAtomicAdd(p, v); }
+#else
 __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
+#endif
 // accumulator update: a fire-and-forget atomic either way -- exchange on the first touch, add afterwards -- so that the later adds of the
 // same wave are ordered behind the replacement at L2 (a plain store takes another path)
 __device__ __forceinline__ void acc_out(float* p, float v, bool first)
 {
+#ifdef TI_EXP_NOATOM
+    if (!ti_exp_never) return;
+#endif
     if (first) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else unsafeAtomicAdd(p, v);
 }
@@ -53,7 +61,10 @@ __host__ __device__ constexpr int edge_chunk4(int NB, bool H16) { return (H16 ? 
 // Does this (feature width, precision) run the one-accumulator split format (mfma_chain.hpp: Opnd1)?  TI_PREC_F16X2 up to F = 128.  The
 // F = 256 build of it (one wave per SIMD, operands partly in AGPRs) faulted on the device in the first GPU run and keeps the
 // two-accumulator format until that is understood; ti_api.hip packs the message streams accordingly.
-__host__ __device__ constexpr bool edge_one_chain(int NB, int PREC) { return PREC == 1 && NB <= 4; }
+#ifndef TI_ONE_CHAIN_MAX_NB
+#define TI_ONE_CHAIN_MAX_NB 4
+#endif
+__host__ __device__ constexpr bool edge_one_chain(int NB, int PREC) { return PREC == 1 && NB <= TI_ONE_CHAIN_MAX_NB; }
 __host__ __device__ constexpr bool edge_build_exists(int NB, int WAVES, int PREC) { return !(PREC == 2 && NB == 1 && WAVES == 8); }
 template <int NBK, bool FIRST, bool LAST, int PREC, int WAVES, int NS>
 __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void painn_edge_kernel(const EdgeParams p)

@@ -523,6 +523,37 @@ hipError_t launch_edge(int NBv, bool first, bool last, int prec, const EdgeParam
     }
 }
 
+// ---- pair-major message kernel: per-atom sums of the partial rows (painn_pair_kernel.hpp writes one row of 7 F floats per block and
+// slot).  One thread per float4 of a node's row; the partial rows of an atom are added in walk order: fixed order, no atomics.
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceParams p)
+{
+    const int per = 7 * p.F / 4, F4 = p.F / 4;                  // float4 per partial row: ds [0, F4), dv [F4, 4 F4), c [4 F4, 7 F4)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long node = t / per;
+    const int f4 = (int)(t - node * per);
+    if (node >= p.B * p.A || (!p.has_c && f4 >= 4 * F4)) return;
+    const long long mol = node / p.A;
+    const int atom = (int)(node - mol * p.A);
+    const long long g = mol / p.G;
+    const int32_t* pl = p.plist + ((size_t)(mol - g * p.G) * p.A + atom) * p.kmax;
+    const f32x4* base = reinterpret_cast<const f32x4*>(p.part) + (size_t)g * p.nblk * 8 * per + f4;
+    f32x4 s = {0, 0, 0, 0};
+    for (int k = 0; k < p.kmax; ++k) {
+        const int id = pl[k];
+        if (id < 0) break;
+        s += base[(size_t)id * per];
+    }
+    if (f4 < F4) reinterpret_cast<f32x4*>(p.dsacc)[(size_t)node * F4 + f4] = s;
+    else if (f4 < 4 * F4) reinterpret_cast<f32x4*>(p.dvacc)[(size_t)node * 3 * F4 + (f4 - F4)] = s;
+    else reinterpret_cast<f32x4*>(p.cacc)[(size_t)node * 3 * F4 + (f4 - 4 * F4)] = s;
+}
+hipError_t launch_pair_reduce(const PairReduceParams& p, hipStream_t st)
+{
+    const long long threads = p.B * p.A * (7 * p.F / 4);
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair(int NBv, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st)
 {
     switch (NBv) {

@@ -14,6 +14,13 @@
 //     and J slots r = 0..3.  Direction B (dst = I[q]) is an in-lane sum of the four registers; direction A (dst = J[r]) is the sum over
 //     the four lane rows, two v_permlane swap levels that leave slot q' in lane row q'.  Rows of pairs that do not exist are zeroed
 //     through the shared w factor (which also carries 1 / (S_phi S_w) of the one-accumulator format).
+//   * NO ATOMICS.  The directed kernel adds its per-atom sums and `e += de` with fire-and-forget float atomics; measured
+//     (profiles/r03a_atomics_experiment.txt), those dword atomics -- ~1 per L2 channel and clock, 4.9e9 per launch -- are 13.6 of its
+//     31.3 ms, and a pair-major kernel built the same way (8.3e9 of them: every slot of a 4 x 4 tile holds only four rows) sat at 30.0 ms
+//     against 12.0 ms without them.  Here every (block, slot) writes its partial sum of ds / dv / c with plain stores into its own row
+//     of a partial-sum buffer (`part`), and `pair_reduce_kernel` adds each atom's rows in walk order (ti_internal.hpp; deterministic,
+//     nothing to zero); the edge state is updated in the ROW layout (the de slice with the operands the other way round, like the fp16
+//     storage mode of the directed kernel): each e row has one owner, so e += de is a 16-byte load and store per lane.
 // Per 32 directed edges: 84 chunk products and 56 chunk visits instead of 112 and 112, six LayerNorm / SiLU / operand-split phases
 // instead of eight.  What it costs: 4 x 4 tiles cover a complete graph of A atoms with (A - 1) / (4 * ceil((A - 1) / 4)) of their rows
 // at best (ti_api.hip: build_pair_template; 85 % for 18 atoms), and every atom's accumulators are touched from ~ (A - 1) / 4 blocks.
@@ -50,18 +57,41 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
+#ifndef TI_EXP_MEM
+#define TI_EXP_MEM 0      // experiment builds only (tools/variant_bench.py): fold addresses onto a few groups so that the traffic stays in L2
+#endif
+    // bit 0: partial-sum stores, bit 1: e stores, bit 2: P / v / x gathers, bit 3: e / enc / geo loads
+    const long long gi_ps = (TI_EXP_MEM & 1) ? (gi & 7) : gi, gi_es = (TI_EXP_MEM & 2) ? (gi & 7) : gi;
+    const long long gi_g = (TI_EXP_MEM & 4) ? (gi & 7) : gi, gi_el = (TI_EXP_MEM & 8) ? (gi & 7) : gi;
     auto node_of = [&](int mol_local, int atom) {
-        long long m = gi * p.G + mol_local;
+        long long m = gi_g * p.G + mol_local;
         m = m < p.B ? m : p.B - 1;
         return m * p.A + atom;
     };
 
+    // Diagnostic build only (-DTI_STAMPS; never the product): shader-clock stamps of ONE row block of a few workgroups, and one
+    // (s_memtime, s_memrealtime) pair around the whole block loop of every wave for the in-kernel clock (MI355X guide, DVFS item 6).
+    // Stamps go to a buffer of their own that nothing else reads.
+#ifdef TI_STAMPS
+    constexpr int STAMP_SLOTS = 64;
+    const bool st_wg = blockIdx.x >= 300 && blockIdx.x < 304;
+    unsigned long long* const st_buf = p.stamps ? p.stamps + ((size_t)(blockIdx.x - 300) * WAVES + wave) * STAMP_SLOTS : nullptr;
+    int st_i = 0;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (p.stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#define TI_STAMP() do { if (st_wg && st_buf && blk == 3 && st_i < STAMP_SLOTS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) st_buf[st_i] = t_; ++st_i; } } while (0)
+#else
+#define TI_STAMP() do { } while (0)
+#endif
+
     for (int blk = 0; blk < p.nblk; ++blk) {
+        TI_STAMP();
         // ---- K1 geometry of this lane's pair row (the 4 quarters compute the same row); direction A: r = x[I] - x[J]
         const uint32_t meta = p.rows[blk * 16 + j];
         const long long nI = node_of(prow_molI(meta), prow_atomI(meta)), nJ = node_of(prow_molJ(meta), prow_atomJ(meta));
-        const size_t brow0 = ((size_t)gi * p.nblk + blk) * 16;          // pair rows: parked encoding / edge_dir
+        const size_t brow0 = ((size_t)gi_el * p.nblk + blk) * 16;       // pair rows: parked encoding / edge_dir
         const size_t erowA = brow0 * 2, erowB = erowA + 16;             // e rows of the two directions
+        const size_t srowA = ((size_t)gi_es * p.nblk + blk) * 32, srowB = srowA + 16;      // (the same rows: where e is stored)
         OP enc;
         f32x4* const enc_park = reinterpret_cast<f32x4*>(p.enc) + (brow0 / 16) * (sizeof(OP) / 16) * 64 + lane;
         f32x4* const geo_park = reinterpret_cast<f32x4*>(p.geo) + brow0 + j;
@@ -84,6 +114,7 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
             if (q == 0) *reinterpret_cast<f32x4*>(scratch + j * 4) = *geo_park;
             r16::opnd_load(enc, enc_park);
         }
+        TI_STAMP();
         // ---- w(enc(d)) hidden layers, once per pair
         OP g2;
         {
@@ -96,8 +127,10 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
+            TI_STAMP();
             r16::ln_silu(t1, vec + EV::W_G0 * F, vec + EV::W_BE0 * F, q, eps_w0);
             g1.set(t1);
+            TI_STAMP();
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 f32x4 a0 = r16::load_block(vec + EV::W_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::W_B1 * F, 2 * c + 1, q);
@@ -105,8 +138,10 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 t1.b[2 * c] = a0; t1.b[2 * c + 1] = a1;
                 pipe.release();
             }
+            TI_STAMP();
             r16::ln_silu(t1, vec + EV::W_G1 * F, vec + EV::W_BE1 * F, q, eps_w1);
             g2.set(t1);
+            TI_STAMP();
         }
         // ---- phi([s[src] | e]) hidden layers of both directions in lock step; the s[src] half of the first Linear is P[src]
         OP h2A, h2B;
@@ -125,6 +160,7 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 scB = inB.set_scaled(tB);
             }
             const float ivA = r16::pow2_inverse(scA) * s_p0, ivB = r16::pow2_inverse(scB) * s_p0;
+            TI_STAMP();
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 f32x4 a0 = r16::load_state<false>(p.P, (size_t)nI * F, 2 * c, q) * ivA, a1 = r16::load_state<false>(p.P, (size_t)nI * F, 2 * c + 1, q) * ivA;
@@ -134,9 +170,11 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 tB.b[2 * c] = b0 * scB; tB.b[2 * c + 1] = b1 * scB;
                 pipe.release();
             }
+            TI_STAMP();
             r16::ln_silu(tA, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q, eps_p0);
             r16::ln_silu(tB, vec + EV::P_G0 * F, vec + EV::P_BE0 * F, q, eps_p0);
             inA.set(tA); inB.set(tB);
+            TI_STAMP();
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 f32x4 a0 = r16::load_block(vec + EV::P_B1 * F, 2 * c, q), a1 = r16::load_block(vec + EV::P_B1 * F, 2 * c + 1, q);
@@ -146,9 +184,11 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 tB.b[2 * c] = b0; tB.b[2 * c + 1] = b1;
                 pipe.release();
             }
+            TI_STAMP();
             r16::ln_silu(tA, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q, eps_p1);
             r16::ln_silu(tB, vec + EV::P_G1 * F, vec + EV::P_BE1 * F, q, eps_p1);
             h2A.set(tA); h2B.set(tB);
+            TI_STAMP();
         }
         // ---- output layer, flipped: features on lanes (l & 15), pair rows 4q + r in registers: I slot q, J slots r
         uint32_t mi[4];
@@ -157,15 +197,11 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
         f32x4 wfac;                                      // row mask x 1 / (S_phi S_w): rides on the shared w factor
 #pragma unroll
         for (int r = 0; r < 4; ++r) wfac[r] = (mi[r] & 1u) ? inv_out : 0.0f;
-        int qnA, qnB;                                    // accumulator node of this lane row: direction A adds to J[q], direction B to I[q]
-        bool qfA, qfB;
-        {
-            const int snI = p.slotnode[blk * 16 + q], snJ = p.slotnode[blk * 16 + 4 + q];
-            const long long mA = gi * p.G + slot_mol(snJ), mB = gi * p.G + slot_mol(snI);
-            qnA = (snJ >= 0 && group_ok && mA < p.B) ? (int)(mA * p.A + (snJ & 255)) : -1;
-            qnB = (snI >= 0 && group_ok && mB < p.B) ? (int)(mB * p.A + (snI & 255)) : -1;
-            qfA = (snJ & SLOT_FIRST_TOUCH) != 0; qfB = (snI & SLOT_FIRST_TOUCH) != 0;
-        }
+        // partial-sum rows of this lane row: direction A's sums belong to J slot q (row 4 + q of the block's eight), direction B's to I slot q
+        float* const part_blk = p.part + ((size_t)gi_ps * p.nblk + blk) * 8 * (7 * F);
+        const bool haveA = group_ok && p.slotnode[blk * 16 + 4 + q] >= 0, haveB = group_ok && p.slotnode[blk * 16 + q] >= 0;
+        float* const partA = part_blk + (size_t)(4 + q) * (7 * F);
+        float* const partB = part_blk + (size_t)q * (7 * F);
         const long long nIq = node_of(prow_molI(mi[0]), prow_atomI(mi[0]));      // source of direction A for all four rows of this lane
 
         // (phi_c + b) of both directions times the shared (w_c + b) for output slice c (0 gates, 1 scale_edge_dir, 2 ds, 3 de,
@@ -187,45 +223,60 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
             using QS = r16::QuarterSum<4>;
             return QS::swap32_add(QS::swap16_add(v[0], v[1]), QS::swap16_add(v[2], v[3]));
         };
-        auto emitA = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
+        // off: offset of the quantity inside a partial row (ds 0, dv (1 + c) F, c (4 + c) F) plus the lane's feature
+        auto emitA = [&](const f32x4& v0, const f32x4& v1, int off) {
             const float z0 = sumA(v0), z1 = sumA(v1);
-            if (qnA >= 0) { float* d = dst + (size_t)qnA * stride; acc_out(d, z0, qfA); acc_out(d + 16, z1, qfA); }
+            if (haveA) { partA[off] = z0; partA[off + 16] = z1; }
         };
         // direction B: the four registers of a lane are the J slots of ONE destination I[q]
-        auto emitB = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
+        auto emitB = [&](const f32x4& v0, const f32x4& v1, int off) {
             const float z0 = (v0[0] + v0[1]) + (v0[2] + v0[3]), z1 = (v1[0] + v1[1]) + (v1[2] + v1[3]);
-            if (qnB >= 0) { float* d = dst + (size_t)qnB * stride; acc_out(d, z0, qfB); acc_out(d + 16, z1, qfB); }
+            if (haveB) { partB[off] = z0; partB[off + 16] = z1; }
         };
+        const float wrow = (meta & 1u) ? inv_out : 0.0f;                 // the same row factor in the row layout (lane (j, q): row j)
 
 #pragma unroll 1
         for (int nbo = 0; nbo < NB; ++nbo) {
             const int fo = 32 * nbo + j;
+            TI_STAMP();
             {   // ds: invariant message, summed over incoming edges
                 f32x4 a0, a1, b0, b1;
                 out3(2, nbo, a0, a1, b0, b1);
-                emitA(a0, a1, p.dsacc + fo, F);
-                emitB(b0, b1, p.dsacc + fo, F);
+                emitA(a0, a1, fo);
+                emitB(b0, b1, fo);
             }
-            if constexpr (!LAST) {   // de: edge state update  e += de, both directions
-                f32x4 a0, a1, b0, b1;
-                out3(3, nbo, a0, a1, b0, b1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* ea = p.e + (erowA + 4 * q + r) * F + fo;
-                    float* eb = p.e + (erowB + 4 * q + r) * F + fo;
-                    if (group_ok) {
-                        if (FIRST) {
-                            const float* em = p.edge_emb + prow_type(mi[r]) * F + fo;
-                            const float e0 = em[0], e1 = em[16];
-                            ea[0] = e0 + a0[r]; ea[16] = e1 + a1[r];
-                            eb[0] = e0 + b0[r]; eb[16] = e1 + b1[r];
-                        } else {
-                            add_noret(ea, a0[r]); add_noret(ea + 16, a1[r]);
-                            add_noret(eb, b0[r]); add_noret(eb + 16, b1[r]);
-                        }
-                    }
+            TI_STAMP();
+            if constexpr (!LAST) {
+                // de: edge state update e += de of both directions in the ROW layout (lane (j, q): row j, features 16 (2 nbo) + 4q .. and
+                // 16 (2 nbo + 1) + 4q ..): the same two chunks with the operands the other way round; the old row is loaded before the
+                // products and stored after them -- one owner per row, no atomics
+                f32x4 a0 = r16::load_block(vec + (EV::P_B2 + 3) * F, 2 * nbo, q), a1 = r16::load_block(vec + (EV::P_B2 + 3) * F, 2 * nbo + 1, q);
+                f32x4 b0 = a0, b1 = a1;
+                f32x4 w0 = r16::load_block(vec + (EV::W_B2 + 3) * F, 2 * nbo, q), w1 = r16::load_block(vec + (EV::W_B2 + 3) * F, 2 * nbo + 1, q);
+                float* const ea = p.e + (erowA + j) * F;
+                float* const eb = p.e + (erowB + j) * F;
+                f32x4 oA0, oA1, oB0, oB1;
+                if (FIRST) {
+                    const float* em = p.edge_emb + prow_type(meta) * F;
+                    oA0 = r16::load_block(em, 2 * nbo, q); oA1 = r16::load_block(em, 2 * nbo + 1, q);
+                    oB0 = oA0; oB1 = oA1;
+                } else {
+                    oA0 = r16::load_block(ea, 2 * nbo, q); oA1 = r16::load_block(ea, 2 * nbo + 1, q);
+                    oB0 = r16::load_block(eb, 2 * nbo, q); oB1 = r16::load_block(eb, 2 * nbo + 1, q);
+                }
+                r16::gemm_x2_on_pipe<false>(a0, a1, b0, b1, h2A, h2B, pipe, lane);
+                pipe.release();
+                r16::gemm_on_pipe<false>(w0, w1, g2, pipe, lane);
+                pipe.release();
+                w0 *= wrow; w1 *= wrow;
+                if (group_ok) {
+                    float* const sa = p.e + (srowA + j) * F;
+                    float* const sb = p.e + (srowB + j) * F;
+                    r16::store_block(sa, 2 * nbo, q, oA0 + a0 * w0); r16::store_block(sa, 2 * nbo + 1, q, oA1 + a1 * w1);
+                    r16::store_block(sb, 2 * nbo, q, oB0 + b0 * w0); r16::store_block(sb, 2 * nbo + 1, q, oB1 + b1 * w1);
                 }
             }
+            TI_STAMP();
             {   // equivariant message: sum_e (sed * dir_e + gates * v[src_e]) -> dvacc ; sum_e cg * dir_e -> cacc
                 f32x4 sA0, sA1, sB0, sB1, gA0 = {0, 0, 0, 0}, gA1 = {0, 0, 0, 0}, gB0 = {0, 0, 0, 0}, gB1 = {0, 0, 0, 0};
                 out3(1, nbo, sA0, sA1, sB0, sB1);
@@ -247,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                         v0[r] = sA0[r] * dir[r][c]; v1[r] = sA1[r] * dir[r][c];
                         if (!FIRST) { v0[r] = fmaf(gA0[r], vA[c][0], v0[r]); v1[r] = fmaf(gA1[r], vA[c][1], v1[r]); }
                     }
-                    emitA(v0, v1, p.dvacc + c * F + fo, 3 * F);
+                    emitA(v0, v1, (1 + c) * F + fo);
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -260,8 +311,9 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                             v0[r] = fmaf(gB0[r], vp[0], v0[r]); v1[r] = fmaf(gB1[r], vp[16], v1[r]);
                         }
                     }
-                    emitB(v0, v1, p.dvacc + c * F + fo, 3 * F);
+                    emitB(v0, v1, (1 + c) * F + fo);
                 }
+                TI_STAMP();
                 if (!FIRST) {
                     f32x4 cA0, cA1, cB0, cB1;
                     out3(4, nbo, cA0, cA1, cB0, cB1);
@@ -270,20 +322,27 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                         f32x4 v0, v1;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v0[r] = cA0[r] * dir[r][c]; v1[r] = cA1[r] * dir[r][c]; }
-                        emitA(v0, v1, p.cacc + c * F + fo, 3 * F);
+                        emitA(v0, v1, (4 + c) * F + fo);
                     }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         f32x4 v0, v1;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v0[r] = -(cB0[r] * dir[r][c]); v1[r] = -(cB1[r] * dir[r][c]); }
-                        emitB(v0, v1, p.cacc + c * F + fo, 3 * F);
+                        emitB(v0, v1, (4 + c) * F + fo);
                     }
                 }
             }
         }
     }
     pipe.drain();
+#ifdef TI_STAMPS
+    if (p.stamps && lane == 0) {          // whole-loop clock pair of every wave: [4 * WAVES * STAMP_SLOTS + 2 * wave id ...]
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* c = p.stamps + (size_t)4 * WAVES * STAMP_SLOTS + 2 * (size_t)gi_raw;
+        c[0] = clk1 - clk0; c[1] = rt1 - rt0;
+    }
+#endif
 }
 
 template <int NB, int EW, int PREC>

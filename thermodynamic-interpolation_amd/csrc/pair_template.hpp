@@ -26,10 +26,11 @@ struct PairTemplate {
     std::vector<uint32_t> rows;              // [nblk * 16] row words
     std::vector<int32_t> slotnode;           // [nblk * 16] slot words (k = 0..3 I slots, 4..7 J slots, rest unused = -1)
     std::vector<int> pair_pos;               // [(m * A + src) * A + dst] -> (block * 2 + direction) * 16 + pair row, -1 = no such edge
+    // The kernel writes, per block and slot, the partial sum of that slot's rows (plain stores, no atomics); plist names, per atom of the
+    // group, the partial rows that belong to it, in walk order: [(m * A + atom) * kmax + k] = block * 8 + slot, -1 = end of the list
+    std::vector<int32_t> plist; int kmax = 0;
     double fill = 0.0;                       // valid rows / all rows
 };
-
-constexpr int32_t PAIR_SLOT_FIRST_TOUCH = 1 << 30;      // == ti::SLOT_FIRST_TOUCH (ti_internal.hpp)
 
 namespace pair_detail {
 struct Blk {
@@ -42,9 +43,8 @@ struct Blk {
 }  // namespace pair_detail
 
 // src / dst / etype: the E directed edges of ONE molecule (A <= 32 atoms).  Returns false (no pair template) when the directed graph
-// is not the symmetric closure of an undirected one with one type per pair.  first_touch: mark, per accumulator slot, the first
-// block (in walk order; inside a block the J slots before the I slots) that touches an atom.
-inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t* dst, const int32_t* etype, bool first_touch, PairTemplate& out)
+// is not the symmetric closure of an undirected one with one type per pair.
+inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t* dst, const int32_t* etype, PairTemplate& out)
 {
     using pair_detail::Blk;
     if (E <= 0 || (E & 1) || A > 32) return false;
@@ -149,7 +149,7 @@ inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t*
     out.G = G; out.nblk = nblk;
     out.rows.assign((size_t)nblk * RB, 0u); out.slotnode.assign((size_t)nblk * RB, -1);
     out.pair_pos.assign((size_t)G * A * A, -1);
-    std::vector<char> done((size_t)G * A * A, 0), touched((size_t)G * 32, 0);
+    std::vector<char> done((size_t)G * A * A, 0);
     size_t n_valid = 0;
     for (int bi = 0; bi < nblk; ++bi) {
         const Blk& b = best[bi];
@@ -173,21 +173,23 @@ inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t*
                     out.pair_pos[((size_t)m * A + j) * A + i] = (bi * 2 + 1) * RB + 4 * a + c;       // direction B: J[c] -> I[a]
                 }
             }
-        // accumulator order inside a block: direction A (the J slots) first, then direction B (the I slots).  A slot whose rows are all
-        // invalid still replaces / adds a zero sum: harmless.
-        for (int k = 0; k < 4; ++k)
-            if (b.J[k] >= 0) {
-                const int32_t first = (first_touch && !touched[b.J[k]]) ? PAIR_SLOT_FIRST_TOUCH : 0;
-                touched[b.J[k]] = 1;
-                out.slotnode[(size_t)bi * RB + 4 + k] = first | ((b.J[k] / 32) << 8) | (b.J[k] % 32);
-            }
-        for (int k = 0; k < 4; ++k)
-            if (b.I[k] >= 0) {
-                const int32_t first = (first_touch && !touched[b.I[k]]) ? PAIR_SLOT_FIRST_TOUCH : 0;
-                touched[b.I[k]] = 1;
-                out.slotnode[(size_t)bi * RB + k] = first | ((b.I[k] / 32) << 8) | (b.I[k] % 32);
-            }
+        for (int k = 0; k < 4; ++k) {
+            if (b.I[k] >= 0) out.slotnode[(size_t)bi * RB + k] = ((b.I[k] / 32) << 8) | (b.I[k] % 32);
+            if (b.J[k] >= 0) out.slotnode[(size_t)bi * RB + 4 + k] = ((b.J[k] / 32) << 8) | (b.J[k] % 32);
+        }
     }
+    // partial-sum lists per atom: slot k of block bi (k < 4: the I slots = direction B's destinations; k >= 4: the J slots = direction
+    // A's), in walk order -- the order the reduction adds them in
+    std::vector<std::vector<int32_t>> lists((size_t)G * A);
+    for (int bi = 0; bi < nblk; ++bi)
+        for (int k = 0; k < 8; ++k) {
+            const int key = k < 4 ? best[bi].I[k] : best[bi].J[k - 4];
+            if (key >= 0) lists[(size_t)(key / 32) * A + key % 32].push_back(bi * 8 + k);
+        }
+    out.kmax = 1;
+    for (auto& l : lists) out.kmax = std::max(out.kmax, (int)l.size());
+    out.plist.assign((size_t)G * A * out.kmax, -1);
+    for (size_t a = 0; a < lists.size(); ++a) std::copy(lists[a].begin(), lists[a].end(), out.plist.begin() + a * out.kmax);
     if (n_valid * 2 != (size_t)G * E) throw std::logic_error("pair template: not every edge was placed exactly once");
     out.fill = (double)n_valid / ((double)nblk * RB);
     return true;

@@ -166,6 +166,8 @@ struct ti_handle {
     // exists for this width / precision.  pair_pos[(m * A + src) * A + dst] = e row of that directed edge of molecule-in-group m inside
     // its group: (block * 2 + direction) * 16 + pair row
     bool has_pair = false; std::vector<int> pair_pos; double pair_fill = 0.0;
+    DevBuf<int32_t> pair_plist; int pair_kmax = 0;     // per atom of a group: its partial-sum rows (pair_template.hpp)
+    DevBuf<float> part;                                // [groups * nblk][8][7 F] partial sums of the pair-major kernel
     int n_tpl = 1, active = 0, parts = 1, max_slots = 0, pinned_tpl = TI_TEMPLATE_AUTO;
     // every atom has incoming edges: the edge kernels' first touch of an accumulator replaces its contents (ti_internal.hpp
     // SLOT_FIRST_TOUCH) and nothing zeroes the accumulators between layers or calls; otherwise the update kernel zeroes them as before
@@ -354,11 +356,12 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
 static bool build_pair_template(ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype)
 {
     ti::PairTemplate pt;
-    if (!ti::build_pair_template(h->d.n_atoms, h->d.n_edges, src, dst, etype, h->first_touch, pt)) return false;
+    if (!ti::build_pair_template(h->d.n_atoms, h->d.n_edges, src, dst, etype, pt)) return false;
     ti_handle::Tpl& T = h->tpl[2];
     T.G = pt.G; T.P = 1; T.nblk = pt.nblk; T.max_slots = 4;
     T.rows.upload(pt.rows); T.slotnode.upload(pt.slotnode);
     h->pair_pos = pt.pair_pos; h->pair_fill = pt.fill;
+    h->pair_plist.upload(pt.plist); h->pair_kmax = pt.kmax;
     return true;
 }
 
@@ -580,6 +583,7 @@ void ensure_painn_ws(ti_handle* h, long long B)
     // parked geometry of a drift evaluation (painn_edge_kernel.hpp): the encoding operand of every edge row (as many bytes as e) and edge_dir
     h->enc.alloc((edge_rows_for(h, B) * F + se - 1) / se); h->geo.alloc(edge_rows_for(h, B) * 4);
     h->divb.alloc(B); h->div2.alloc(B); h->dl.alloc(B); h->dlscaled.alloc(B);
+    if (h->has_pair) h->part.alloc((size_t)((B + h->tpl[2].G - 1) / h->tpl[2].G) * h->tpl[2].nblk * 8 * 7 * F);
     h->cap = B;
 }
 
@@ -713,8 +717,36 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
                 for (int i = 0; i < 6; ++i) p.wscale[i] = h->edge_scale[(size_t)l * 6 + i];
             }
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
-            if (h->active == 2) HIP_CHECK(launch_pair(NB, l == 0, l == L - 1, prec, p, st));
-            else HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
+            if (h->active == 2) {
+                p.part = h->part.p;
+#ifdef TI_STAMPS      // diagnostic build only: stamps of layer 2's launch, printed to stderr (tools/stamps.py reads them)
+                static DevBuf<unsigned long long> stamp_buf;
+                const size_t n_st = 4 * 8 * 64 + 2 * (size_t)groups + 16;
+                if (l == 2 && std::getenv("TI_STAMPS_DUMP")) { if (stamp_buf.n < n_st) stamp_buf.alloc(n_st); HIP_CHECK(hipMemsetAsync(stamp_buf.p, 0, n_st * 8, st)); p.stamps = stamp_buf.p; }
+#endif
+                HIP_CHECK(launch_pair(NB, l == 0, l == L - 1, prec, p, st));
+#ifdef TI_STAMPS
+                if (p.stamps) {
+                    std::vector<unsigned long long> hs(n_st);
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    HIP_CHECK(hipMemcpy(hs.data(), stamp_buf.p, n_st * 8, hipMemcpyDeviceToHost));
+                    const int EWv = groups >= 2048 && prec == 1 ? 8 : 4;
+                    for (int w = 0; w < 4 * EWv; ++w) {
+                        std::fprintf(stderr, "STAMP %d:", w);
+                        for (int k = 1; k < 64 && hs[(size_t)w * 64 + k]; ++k) std::fprintf(stderr, " %llu", hs[(size_t)w * 64 + k] - hs[(size_t)w * 64 + k - 1]);
+                        std::fprintf(stderr, "\n");
+                    }
+                    std::vector<double> clk;
+                    for (long long g2 = 0; g2 < groups; ++g2) { const auto c = hs[(size_t)4 * EWv * 64 + 2 * g2], r = hs[(size_t)4 * EWv * 64 + 2 * g2 + 1]; if (r) clk.push_back(100e6 * (double)c / (double)r); }
+                    std::sort(clk.begin(), clk.end());
+                    if (!clk.empty()) std::fprintf(stderr, "INKERNEL_CLOCK_GHZ median %.4f  p10 %.4f  p90 %.4f  waves %zu\n", clk[clk.size() / 2] / 1e9, clk[clk.size() / 10] / 1e9, clk[clk.size() * 9 / 10] / 1e9, clk.size());
+                }
+#endif
+                PairReduceParams r{};
+                r.part = h->part.p; r.plist = h->pair_plist.p; r.kmax = h->pair_kmax; r.G = h->G; r.A = A; r.F = F; r.nblk = h->nblk;
+                r.has_c = l > 0; r.B = B; r.dsacc = h->dsacc.p; r.dvacc = h->dvacc.p; r.cacc = h->cacc.p;
+                HIP_CHECK(launch_pair_reduce(r, st));
+            } else HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
         }
         if (h->tap == 1 + 2 * l) return;
         if (jr) {

@@ -44,8 +44,9 @@ __host__ __device__ inline int row_slot(uint32_t w) { return (w >> 18) & 63; }
 // J[b] -> I[a].  The per-atom sums need no masks: direction B's destination is the same for the four rows a lane holds (in-lane adds),
 // direction A's is the same across the four lane rows (two lane-swap levels).
 //   row word : bit0 valid | molI<<1 (3b) | atomI<<4 (5b) | molJ<<9 (3b) | atomJ<<12 (5b) | etype<<17 (2b)     (empty slots: a safe atom)
-//   slot word: slotnode[blk*16 + k], k = 0..3 the I slots, k = 4..7 the J slots: -1, or atom | mol<<8 | SLOT_FIRST_TOUCH
-// Within a block, for any accumulator element, direction A's contribution is issued before direction B's (first-touch order).
+//   slot word: slotnode[blk*16 + k], k = 0..3 the I slots, k = 4..7 the J slots: -1, or atom | mol<<8
+// No atomics: slot k of block b writes the sum over its rows of (ds | dv | c) into partial row b*8 + k of its group; a reduction
+// (pair_reduce_kernel) adds, per atom, the partial rows the template lists for it (plist), in walk order.
 // e rows: [group][block][direction][16][F]; the parked encoding / edge_dir (direction A's) once per pair: [group][block][16].
 constexpr int PAIR_MAX_G = 8;
 __host__ __device__ inline int prow_molI(uint32_t w) { return (w >> 1) & 7; }
@@ -77,7 +78,18 @@ struct EdgeParams {
     float* enc;                             // [n_groups*nblk][operand registers][64] parked encoding operand of every row block (layer 0 writes, the others read)
     float wscale[6];                        // TI_PREC_F16X2: powers of two the host scaled w.W0, w.W1, phi.W0(e), phi.W1, phi.W2, w.W2 by (else 1)
     float* geo;                             // [n_groups*nblk*16][4] parked edge_dir
+    float* part;                            // pair-major kernel: [n_groups*nblk][8 slots][7][F] partial sums (ds | dv x3 | c x3) of every slot
+    unsigned long long* stamps;             // diagnostic builds (-DTI_STAMPS) only: s_memtime / s_memrealtime stamps, a buffer of their own; else NULL
 };
+
+// pair-major kernel: sum of each atom's partial rows (walk order) -> dsacc / dvacc / cacc, which the update kernel then reads
+struct PairReduceParams {
+    const float* part; const int32_t* plist;        // plist [G*A][kmax]: partial rows (block * 8 + slot) of every atom of a group, -1 = end
+    int kmax, G, A, F, nblk, has_c;                 // has_c = 0: the first layer writes no cross-gate sums
+    long long B;
+    float *dsacc, *dvacc, *cacc;
+};
+hipError_t launch_pair_reduce(const PairReduceParams& p, hipStream_t st);
 
 struct EmbedParams {
     const float4* stream; int nch;
