@@ -403,6 +403,10 @@ def lnaff_cases():
         # (1e3 on the FIRST LayerNorm of each MLP only: on both, the reference itself overflows to NaN within two layers)
         painn_case(f"lnaff_{tag}_f32", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=31, intermediates=True, recipe=recipe(f, 2, which=which))
         painn_case(f"lnaff_{tag}_f128", W.AMBIENT, 128, 2, 5, 2, fc(5), 100, TEMPS, seed=32, intermediates=True, recipe=recipe(f, 2, which=which))
+    # near-zero message matrices beside untouched O(0.1) biases (a pruned / freshly initialised layer): the per-matrix power of two of
+    # the one-accumulator weight format must not be derived from the weights alone (it multiplies the bias row as well)
+    painn_case("lnaff_zero_w_f32", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=35, intermediates=True,
+               recipe=[("phi.mlp.3.weight", 1e-15), ("w.mlp.0.weight", 1e-15), ("w.mlp.6.weight", 1e-12)])
     painn_case("lnaff_harsh_f32", W.AMBIENT, 32, 2, 6, 3, fc(6), 100, TEMPS, seed=33, intermediates=True, recipe=recipe(1e-5, 2, True))
     painn_case("lnaff_harsh_f128", W.AMBIENT, 128, 2, 5, 2, fc(5), 100, TEMPS, seed=34, intermediates=True, recipe=recipe(1e-5, 2, True))
 

@@ -201,6 +201,65 @@ def test_two_rank_sharded_run_equals_single_process_bit_for_bit():
         np.testing.assert_array_equal(outs[r], want[0])
 
 
+def _rccl_worker(port, n_total, q):
+    """Fresh process: the RCCL communicator is created before anything else touches the GPU; the gather runs on GPU tensors."""
+    import torch as th
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    th.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=th.device("cuda", 0))          # "nccl" is RCCL on ROCm
+    try:
+        ti = importlib.import_module("thermodynamic-interpolation_amd")
+        syn, W = ti.synthetic, ti.weights
+        A, F, L = 18, 32, 2
+        tpl = syn.fully_connected_template(A)
+        flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 3), W.painn_param_spec(W.AMBIENT, F, L, 25))
+        eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *tpl, np.arange(A), flat, temp_length=100.0, precision="f16x2")
+        which = ti.distributed.pin_template(eng, n_total)
+        x0 = th.from_numpy(syn.molecule_coords(n_total, A, seed=9)).cuda()
+        cond = th.from_numpy(syn.ambient_cond(n_total, A)).cuda()
+        grid = ti.engine.time_grid(0.0, 1.0, 4)
+
+        def roll(xl, cl, off):              # device tensors in, device tensor out: nothing is staged through the host
+            out, _ = eng.rollout(xl, cl, grid, scheme="em", eps=0.02, seed=7, traj_offset=off, save_every=0)
+            assert out.is_cuda
+            return out[0]
+        full = ti.distributed.rollout_sharded(roll, x0, cond)
+        assert full.is_cuda
+        t = th.ones(4, device="cuda")
+        dist.all_reduce(t)                  # one more collective on the same communicator
+        q.put((which, dist.get_backend(), float(t.sum()), full.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_gather_path_runs_on_hardware_at_world_size_one():
+    """bench.py's N > 1 path -- init_process_group("nccl") then distributed.rollout_sharded / gather_trajectories on GPU tensors -- had
+    only ever run over gloo on host copies (one-GPU boxes).  World size 1 needs no second GPU: the communicator, the all-gather on
+    device buffers and the sharded driver execute on RCCL, and the result equals the plain engine's bit for bit.  (No scaling curve
+    follows from this; it removes "never executed" from the multi-GPU path.)"""
+    import torch.multiprocessing as mp
+    ti = pkg()
+    n_total = 2100
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), n_total, q))
+    p.start()
+    which, backend, s4, got = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and backend == "nccl" and s4 == 4.0
+    syn, W = ti.synthetic, ti.weights
+    A, F, L = 18, 32, 2
+    flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 3), W.painn_param_spec(W.AMBIENT, F, L, 25))
+    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, *syn.fully_connected_template(A), np.arange(A), flat, temp_length=100.0, precision="f16x2")
+    assert eng.template_for(n_total) == which
+    want, _ = eng.rollout(syn.molecule_coords(n_total, A, seed=9), syn.ambient_cond(n_total, A), ti.engine.time_grid(0.0, 1.0, 4), scheme="em",
+                          eps=0.02, seed=7, save_every=0)
+    np.testing.assert_array_equal(got, want[0])
+
+
 def test_engine_on_the_highest_device_index():
     """device > 0 (never exercised on the one-GPU boxes of round 1): create on the last visible GPU and compare with device 0."""
     ti = pkg()

@@ -453,12 +453,14 @@ def test_magnitude_edge_cases_vs_reference(name, precision):
 
 
 LNAFF_CASES = ["lnaff_1em5_f32", "lnaff_1em5_f128", "lnaff_1em3_f32", "lnaff_1em3_f128", "lnaff_1e3_f32", "lnaff_1e3_f128",
-               "lnaff_harsh_f32", "lnaff_harsh_f128"]
+               "lnaff_harsh_f32", "lnaff_harsh_f128", "lnaff_zero_w_f32"]
 
 
 def check_lnaff_magnitudes(name, g):
     """The fixture really drives the hidden activations (SiLU outputs inside the message / update MLPs) where it says."""
     h = g["im::hidden_absmax"]
+    if "zero_w" in name:
+        return                                              # (a weight-scale case, not an activation-magnitude one)
     if "1em5" in name or "harsh" in name:
         assert h.max() < 6.1e-5                             # every hidden row below fp16's smallest normal number
     elif "1em3" in name:
@@ -598,3 +600,89 @@ def test_atom_without_incoming_edges_keeps_the_zeroing_path(precision):
     got, _ = eng.rollout(x, cond, grid, scheme="euler", save_every=0)
     want, _ = orc.rollout(x, cond, grid, scheme="euler", save_every=0)
     assert rel_l2(got - x, want - x) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- BASELINE.json configs at full batch
+def _full_batch_checks(eng, orc, x, cond, *, scheme, eps, tol, template):
+    """Property checks at a BASELINE.json batch size (the parity proper is the fixture tests' job): finite, bit-identical re-run, a
+    132-molecule slice evaluated alone under the same pinned layout equals the slice of the big run bit for bit, six molecules
+    against the CPU oracle."""
+    ti = pkg()
+    B = x.shape[0]
+    eng.set_template(template)
+    assert eng.template_for(B) == template
+    grid = ti.engine.time_grid(0.0, 1.0, 1001)[:2]
+    kw = dict(scheme=scheme, eps=eps, seed=3, save_every=0)
+    a, nfe = eng.rollout(x, cond, grid, **kw)
+    assert nfe == 1 and np.isfinite(a).all()
+    b, _ = eng.rollout(x, cond, grid, **kw)
+    np.testing.assert_array_equal(a, b)
+    part, _ = eng.rollout(x[:132], None if cond is None else cond[:132], grid, **kw)
+    np.testing.assert_array_equal(part[0], a[0, :132])
+    idx = np.r_[0:3, B - 3:B]
+    d = eng.drift(x[idx], 0.5, None if cond is None else cond[idx])
+    assert rel_l2(d, orc.drift(x[idx], 0.5, None if cond is None else cond[idx], precision=64)) < tol
+
+
+def test_config3_latent_sampler_full_batch():
+    """BASELINE.json configs[2]: mdqm9 latent sampler, 65 536 molecules x 18 atoms, F = 128, L = 5, one ODE (Euler) step."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    F, L, A, B = 128, 5, 18, 65536
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(W.LATENT_MULTI, F, L, 25, 9), W.painn_param_spec(W.LATENT_MULTI, F, L, 25))
+    x, cond = syn.molecule_coords(B, A, seed=2, sigma=1.0), syn.latent_cond(B, A, 800.0)
+    eng = ti.engine.PainnEngine(W.LATENT_MULTI, F, L, A, src, dst, et, np.arange(A), flat, temp_length=75.0, precision="f16x2")
+    orc = oracle.PainnOracle(W.LATENT_MULTI, F, L, A, src, dst, et, np.arange(A), flat, temp_length=75.0)
+    _full_batch_checks(eng, orc, x, cond, scheme="euler", eps=0.0, tol=DRIFT_TOL, template=eng.template_for(B))
+
+
+def test_config4_ambient_sampler_full_batch():
+    """BASELINE.json configs[3] (the bench shape): 65 536 ambient molecules, Euler-Maruyama step over the 6-rung ladder, the layout
+    the library picks for this batch by itself."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    F, L, A, B = 128, 5, 18, 65536
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 0), W.painn_param_spec(W.AMBIENT, F, L, 25))
+    x, cond = syn.molecule_coords(B, A, seed=0), syn.ambient_cond(B, A)
+    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision="f16x2")
+    orc = oracle.PainnOracle(W.AMBIENT, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+    _full_batch_checks(eng, orc, x, cond, scheme="em", eps=0.01, tol=DRIFT_TOL, template=eng.template_for(B))
+
+
+def test_config5_fp16_storage_full_share():
+    """BASELINE.json configs[4]: one GPU's share (131 072 molecules) of the 1 048 576-molecule fp16-node-feature run, one EM step in
+    the separately labelled storage mode (bar 1e-2, tests above)."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    F, L, A, B = 128, 5, 18, 131072
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(W.AMBIENT, F, L, 25, 0), W.painn_param_spec(W.AMBIENT, F, L, 25))
+    x, cond = syn.molecule_coords(B, A, seed=4), syn.ambient_cond(B, A)
+    eng = ti.engine.PainnEngine(W.AMBIENT, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision="f16")
+    orc = oracle.PainnOracle(W.AMBIENT, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
+    _full_batch_checks(eng, orc, x, cond, scheme="em", eps=0.01, tol=1e-2, template="throughput")
+
+
+def test_config2_adw_full_batch():
+    """BASELINE.json configs[1]: 262 144 particles, Euler-Maruyama steps of the 1000-step grid (four of them), HIP MLP drift."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    B = 262144
+    flat = W.flatten_state_dict(syn.adw_state_dict(256, 5, 0), W.adw_param_spec(256, 5), dtype=np.float64)
+    eng, orc = ti.engine.AdwEngine(256, 5, flat, precision="f16x2"), oracle.AdwOracle(256, 5, flat)
+    x = syn.adw_x0(B, 0)
+    b0, b1 = np.full(B, 1.0, np.float32), np.full(B, 1.25, np.float32)
+    grid = ti.engine.time_grid(0.0, 1.0, 1001)[:5]
+    kw = dict(scheme="em", eps=0.05, seed=5, save_every=0)
+    a, nfe = eng.rollout(x, b0, b1, grid, **kw)
+    assert nfe == 4 and np.isfinite(a).all()
+    b, _ = eng.rollout(x, b0, b1, grid, **kw)
+    np.testing.assert_array_equal(a, b)
+    part, _ = eng.rollout(x[:1000], b0[:1000], b1[:1000], grid, **kw)         # noise is keyed by the global particle index
+    np.testing.assert_array_equal(part[0], a[0, :1000])
+    idx = np.r_[0:512, B - 512:B]
+    ref, _ = orc.rollout(x[idx].astype(np.float64), b0[idx], b1[idx], grid, scheme="euler")
+    got, _ = eng.rollout(x[idx], b0[idx], b1[idx], grid, scheme="euler", save_every=0)
+    assert rel_l2(got[0], ref[-1]) < 1e-5

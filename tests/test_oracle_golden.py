@@ -10,7 +10,7 @@ PAINN_CASES = ["ambient_small", "ambient_sparse", "ambient_a9", "ambient_a25", "
                "latent_multi", "latent_single", "latent_full", "latent_ctor",
                "range_big", "range_big_f128", "range_tiny", "range_tiny_f128", "range_close", "range_latent_big",
                "lnaff_1em5_f32", "lnaff_1em5_f128", "lnaff_1em3_f32", "lnaff_1em3_f128", "lnaff_1e3_f32", "lnaff_1e3_f128",
-               "lnaff_harsh_f32", "lnaff_harsh_f128"]
+               "lnaff_harsh_f32", "lnaff_harsh_f128", "lnaff_zero_w_f32"]
 # fp32 tolerance.  SURVEY.md §8c proposed 1e-6, but the reference's own fp32 forward sits 0.4e-6 (F=32) to 6e-6
 # (latent, F=128, unit-variance coordinates) away from exact arithmetic (the oracle's fp64 mode) because of GEMM summation
 # order and sin/cos of large arguments; two fp32 evaluations cannot agree better than that.  So: below the north-star bar

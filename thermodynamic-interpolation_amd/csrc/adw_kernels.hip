@@ -255,7 +255,35 @@ __global__ void split_selftest_kernel(unsigned* out)
             bad += ((dh & 0xffffu) != 0) + ((dh >> 16) != 0) + ((dl & 0xffffu) != 0) + ((dl >> 16) != 0);
         }
     }
+    // the one-accumulator format's split of the same values (Opnd1::quad: unscaled residual, v_fma_mix with the literal -1.0): its own
+    // hand-written sequence with the same half-register-write hazard, so its own bit-for-bit check
+    r16::Opnd1<8> o1;
+    o1.set(x);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const r16::u32x4 hw = __builtin_bit_cast(r16::u32x4, o1.hi[m]), lw = __builtin_bit_cast(r16::u32x4, o1.lo[m]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v0 = x.b[2 * m + (k >> 1)][2 * (k & 1)], v1 = x.b[2 * m + (k >> 1)][2 * (k & 1) + 1];
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            const r16::h2 hr{h0, h1}, lr{(_Float16)(v0 - (float)h0), (_Float16)(v1 - (float)h1)};      // fp16-subnormal residuals included
+            const unsigned dh = hw[k] ^ __builtin_bit_cast(unsigned, hr), dl = lw[k] ^ __builtin_bit_cast(unsigned, lr);
+            bad += ((dh & 0xffffu) != 0) + ((dh >> 16) != 0) + ((dl & 0xffffu) != 0) + ((dl >> 16) != 0);
+        }
+    }
     if (bad) atomicAdd(out, bad);
+    // The one-accumulator format relies on v_mfma_f32_16x16x32_f16 taking fp16 SUBNORMAL inputs at face value (tools/micro/mfma_denorm.hip).
+    // One wave checks it: A = 2^-24 (the smallest subnormal) everywhere, B = 1 -> every output element must be 32 * 2^-24 = 2^-19 exactly.
+    if (gid < 64) {
+        r16::h8 a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = __builtin_bit_cast(_Float16, (unsigned short)1); b[i] = (_Float16)1.0f; }
+        const f32x4 d = r16::mfma16h(a, b, f32x4{0, 0, 0, 0});
+        unsigned wrong = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wrong += d[r] != 1.9073486328125e-06f;
+        if (wrong) atomicAdd(out + 1, wrong);
+    }
 }
 
 static inline dim3 grid1(long long n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }

@@ -133,16 +133,39 @@ struct Pipe {
 // staging registers, no ds_write.  The DMA is issued when the first logical chunk of the current superchunk is released
 // (hipcc drains vmcnt(0) at the next use of an ordinary global load while a DMA is in flight, so it is kept away from
 // the GEMM prologues), and is waited for at the superchunk's closing barrier.
-template <int NB, int T, int SC, int CHUNK4 = 256 * NB>      // CHUNK4: float4 per chunk (128 * NB for the hi-only chunks of the fp16 storage mode)
+// STAGGER (8-wave workgroups: waves w and w + 4 share a SIMD).  With one barrier per superchunk all eight waves run in lock step:
+// both waves of a SIMD sit in their matrix phase together (the pipe is contended, the VALU idles) and then in their LayerNorm /
+// product / reduction phase together (the VALU is contended, the matrix pipe idles) -- in-kernel stamps of the message kernel show a
+// hidden layer taking 16 k cycles per pair of waves for 6 k cycles of matrix work and 9 k of vector work (profiles/r03c_*).  With
+// STAGGER the first-dispatched half of the waves DEFERS the barrier that closes a superchunk to its next acquire(), i.e. to behind the
+// vector phase that follows the products, while the second half keeps it right behind the products: between two barriers the early
+// half runs [products k | vector phase k], the late half [vector phase k-1 | products k] -- the partners of a SIMD are half a phase
+// apart, one on the matrix pipe while the other is on the VALU.  Every wave still executes exactly one barrier per superchunk, both
+// halves read the SAME buffer between two barriers (two buffers suffice), and the prefetch of superchunk k+1 goes to the buffer
+// every wave left before the previous barrier.
+// NBUF buffers: the superchunk that is NBUF - 1 ahead is requested when the first chunk of the current one is released.  In-kernel
+// stamps of the message kernels (profiles/r03c_*) showed every 4-chunk product phase lasting ~7.5 k cycles whatever its matrix work
+// (3 k for the single products, 6 k for the lock-step pair): with two buffers the 64 KB a workgroup requests per superchunk have
+// three chunk times to arrive, and at full occupancy an LDS-DMA of that size takes ~5 k cycles from issue to landed, so the interval
+// between two barriers was the transfer's latency, not the products.  Closing superchunk k only needs superchunk k+1: the wait is
+// `vmcnt((NBUF - 2) * PER)` -- the counter is in issue order, and the NBUF - 2 younger requests (and any younger loads / stores)
+// may stay in flight.
+template <int NB, int T, int SC, int CHUNK4 = 256 * NB, bool STAGGER = false, int NBUF = 2>      // CHUNK4: float4 per chunk (128 * NB for the hi-only chunks of the fp16 storage mode)
 struct PipeDMA {
     static constexpr int CH4 = CHUNK4, SUP4 = CH4 * SC, PER = SUP4 / T;
     static_assert(SUP4 % T == 0, "superchunk must be a multiple of the workgroup's 16-byte lanes");
+    static_assert(NBUF >= 2 && (NBUF - 2) * PER <= 48, "in-flight requests must fit the 6-bit vmcnt");
     const f32x4* __restrict__ g;
     f32x4* base;
-    int nsup, idx, par, sub, wave, lane;
+    int nsup, idx, ahead, buf, sub, wave, lane;       // idx: superchunk being consumed, ahead: the next one to request, buf = idx % NBUF
+    bool defer, pending;                    // STAGGER: this wave closes superchunks lazily / a close is outstanding
 
+#ifndef TI_EXP_KNOB
+#define TI_EXP_KNOB 0     // experiment builds only: 1 no LayerNorm/SiLU arithmetic, 2 no workgroup barrier, 4 no weight DMA after init
+#endif
     __device__ __forceinline__ void dma(const f32x4* src, f32x4* dst) const
     {
+        if ((TI_EXP_KNOB & 4) && idx + sub + ahead != 0) return;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int o = k * T + wave * 64;                 // wave-uniform LDS base; lane i lands at base + 16*i bytes
@@ -152,34 +175,51 @@ struct PipeDMA {
     }
     __device__ __forceinline__ void init(const f32x4* stream, int n_chunks, f32x4* lds, int wave_, int lane_)
     {
-        g = stream; nsup = n_chunks / SC; idx = 0; par = 0; sub = 0; wave = wave_; lane = lane_;
+        g = stream; nsup = n_chunks / SC; idx = 0; buf = 0; sub = 0; wave = wave_; lane = lane_;
         base = lds;
-        dma(g, base);
+        defer = STAGGER && wave_ < T / 128;               // the first half of the waves (SIMD partners are w and w + T/128)
+        pending = false;
+        ahead = 0;
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b) {               // superchunks 0 .. NBUF-2 (the stream is cyclic)
+            dma(g + (size_t)ahead * SUP4, base + b * SUP4);
+            ahead = (ahead + 1 == nsup) ? 0 : ahead + 1;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    __device__ __forceinline__ void close()
+    {
+#ifdef TI_EXP_VMCNT       // experiment builds only: an (incorrect) lax wait, to price the in-order vmcnt drain of older atomics
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TI_EXP_VMCNT) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PER) : "memory");
+#endif
+        if (!(TI_EXP_KNOB & 2)) __syncthreads();
+    }
     // Call once at the very end of a kernel: the last release() has a prefetch in flight that nobody will consume, and an
     // LDS-DMA still in flight when the workgroup retires lands in LDS that may already belong to the next workgroup.
-    __device__ __forceinline__ void drain() const
+    __device__ __forceinline__ void drain()
     {
+        if (STAGGER && pending) { close(); pending = false; }          // every wave executes the same number of barriers
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __device__ __forceinline__ const f32x4* acquire() const { return base + par * SUP4 + sub * CH4; }
+    __device__ __forceinline__ const f32x4* acquire()
+    {
+        if (STAGGER && pending) { close(); pending = false; }
+        return base + buf * SUP4 + sub * CH4;
+    }
     __device__ __forceinline__ void release()
     {
-        if (sub == 0) {
-            const int next = (idx + 1 == nsup) ? 0 : idx + 1;
-            dma(g + (size_t)next * SUP4, base + (par ^ 1) * SUP4);
+        if (sub == 0) {                                   // into the buffer of the superchunk every wave left before the last barrier
+            dma(g + (size_t)ahead * SUP4, base + (buf == 0 ? NBUF - 1 : buf - 1) * SUP4);
+            ahead = (ahead + 1 == nsup) ? 0 : ahead + 1;
         }
         if (++sub == SC) {
-#ifdef TI_EXP_VMCNT       // experiment builds only: an (incorrect) lax wait, to price the in-order vmcnt drain of older atomics
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TI_EXP_VMCNT) : "memory");
-#else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            __syncthreads();
+            if (STAGGER && defer) pending = true;
+            else close();
             idx = (idx + 1 == nsup) ? 0 : idx + 1;
-            par ^= 1; sub = 0;
+            buf = (buf + 1 == NBUF) ? 0 : buf + 1; sub = 0;
         }
     }
 };
@@ -442,6 +482,9 @@ __device__ __forceinline__ void load_set(Act<NBK>& a, const float* p, int q)
 template <int NBK>
 __device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const float* beta, int q, float eps = 1e-5f)
 {
+#if defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 1)
+    return;
+#endif
     constexpr float invF = 1.0f / (16.0f * NBK);
     float sum = 0.f;
 #pragma unroll
@@ -607,7 +650,11 @@ __device__ __forceinline__ void posenc_dual(Act<NBK>& a, Act<NBK>& da, float x_o
 // on the host (pack_chunk16_split) with the same k-slot order; a chunk is still 16 KB at F = 128.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+#if defined(TI_EXP_NOMFMA)      // experiment builds only: everything but the fp16 matrix products (and the fragment reads that feed only them)
+__device__ __forceinline__ f32x4 mfma16h(h8 a, h8 b, f32x4 c) { c[0] += (float)a[0] + (float)b[0]; return c; }
+#else
 __device__ __forceinline__ f32x4 mfma16h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#endif
 
 // exact reciprocal of a power of two (the row scales of Opnd::set_scaled)
 __device__ __forceinline__ float pow2_inverse(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
@@ -847,12 +894,18 @@ __device__ __forceinline__ void gemm_split_chunk1(f32x4& acc0, f32x4& acc1, cons
     for (int s = 0; s < AH; ++s) { fh[s] = wl[(2 * s) * 64 + lane]; fl[s] = wl[(2 * s + 1) * 64 + lane]; }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
+#if !(defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8))
         if (s + AH < STEPS) {
             fh[(s + AH) % (AH + 1)] = wl[(2 * (s + AH)) * 64 + lane];
             fl[(s + AH) % (AH + 1)] = wl[(2 * (s + AH) + 1) * 64 + lane];
         }
+#endif
         __builtin_amdgcn_sched_barrier(0x16);
+#if defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8)      // experiment: one fragment pair per chunk (prices the LDS fragment reads)
+        const h8 wh = fh[0], wlo = fl[0];
+#else
         const h8 wh = fh[s % (AH + 1)], wlo = fl[s % (AH + 1)];
+#endif
         const int m = s % KS;
         f32x4& acc = s < KS ? acc0 : acc1;
         if (FLIP) { acc = mfma16h(in.hi[m], wh, acc); acc = mfma16h(in.lo[m], wh, acc); acc = mfma16h(in.hi[m], wlo, acc); }
@@ -877,12 +930,18 @@ __device__ __forceinline__ void gemm_split_chunk1_x2(f32x4& a0, f32x4& a1, f32x4
     for (int s = 0; s < AH; ++s) { fh[s] = wl[(2 * s) * 64 + lane]; fl[s] = wl[(2 * s + 1) * 64 + lane]; }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
+#if !(defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8))
         if (s + AH < STEPS) {
             fh[(s + AH) % (AH + 1)] = wl[(2 * (s + AH)) * 64 + lane];
             fl[(s + AH) % (AH + 1)] = wl[(2 * (s + AH) + 1) * 64 + lane];
         }
+#endif
         __builtin_amdgcn_sched_barrier(0x16);
+#if defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8)
+        const h8 wh = fh[0], wlo = fl[0];
+#else
         const h8 wh = fh[s % (AH + 1)], wlo = fl[s % (AH + 1)];
+#endif
         const int m = s % KS;
         f32x4& accA = s < KS ? a0 : a1;
         f32x4& accB = s < KS ? b0 : b1;

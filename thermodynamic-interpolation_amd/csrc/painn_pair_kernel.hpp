@@ -32,6 +32,14 @@
 namespace ti {
 
 __host__ __device__ constexpr bool pair_build_exists(int NB, int WAVES, int PREC) { return PREC != 2 && NB <= 4 && (WAVES == 4 || WAVES == 8); }
+// weight ring (mfma_chain.hpp PipeDMA): 2-chunk superchunks; the 8-wave build (one workgroup per CU) keeps four of them, i.e. requests
+// the stream three superchunks ahead (128 KB at F = 128), the 4-wave build (two workgroups per CU) two
+#ifndef TI_PAIR_NBUF
+#define TI_PAIR_NBUF 4
+#endif
+__host__ __device__ constexpr int pair_superchunk() { return 2; }
+__host__ __device__ constexpr int pair_ring(int WAVES) { return WAVES == 8 ? TI_PAIR_NBUF : 2; }
+static size_t pair_lds_bytes(int NB, int WAVES) { return (size_t)pair_ring(WAVES) * pair_superchunk() * edge_chunk4(NB, false) * 16 + WAVES * 256 + 21 * (size_t)32 * NB * 4; }
 
 template <int NBK, bool FIRST, bool LAST, int PREC, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(const EdgeParams p)
@@ -43,12 +51,15 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
     using OP = std::conditional_t<ONE, r16::Opnd1<NBK>, typename r16::OpSel<NBK, PREC>::type>;
     extern __shared__ f32x4 lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
-    constexpr int SC = edge_superchunk(NB, WAVES, false);
-    float* scratch = reinterpret_cast<float*>(lds + 2 * SC * CH4) + wave * 64;     // [16 pair rows][4] edge_dir of direction A
-    float* vec = reinterpret_cast<float*>(lds + 2 * SC * CH4) + WAVES * 64;        // [EV::COUNT][F]
+    constexpr int SC = pair_superchunk(), NBUF = pair_ring(WAVES);
+    float* scratch = reinterpret_cast<float*>(lds + NBUF * SC * CH4) + wave * 64;  // [16 pair rows][4] edge_dir of direction A
+    float* vec = reinterpret_cast<float*>(lds + NBUF * SC * CH4) + WAVES * 64;     // [EV::COUNT][F]
     for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
-    PipeDMA<NB, T, SC, CH4> pipe;
+#ifndef TI_PAIR_STAGGER
+#define TI_PAIR_STAGGER 1
+#endif
+    PipeDMA<NB, T, SC, CH4, WAVES == 8 && TI_PAIR_STAGGER, NBUF> pipe;        // 8 waves: SIMD partners half a phase apart (mfma_chain.hpp)
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
     const float eps_w0 = ONE ? 1e-5f * p.wscale[0] * p.wscale[0] : 1e-5f, eps_w1 = ONE ? 1e-5f * p.wscale[1] * p.wscale[1] : 1e-5f;
@@ -350,7 +361,7 @@ static hipError_t configure_pair_prec()
 {
     if constexpr (!pair_build_exists(NB, EW, PREC)) return hipSuccess;
     else {
-    const size_t be = edge_lds_bytes(NB, EW, false);
+    const size_t be = pair_lds_bytes(NB, EW);
     hipError_t e;
     if ((e = set_lds_edge(painn_pair_kernel<2 * NB, true, false, PREC, EW>, be)) != hipSuccess) return e;
     if ((e = set_lds_edge(painn_pair_kernel<2 * NB, false, false, PREC, EW>, be)) != hipSuccess) return e;
@@ -373,7 +384,7 @@ static void launch_pair_p(bool first, bool last, const EdgeParams& p, hipStream_
 {
     if constexpr (pair_build_exists(NB, EW, PREC)) {
     const dim3 g((unsigned)((p.n_groups + EW - 1) / EW)), t(64 * EW);          // one wave = one group of G molecules
-    const size_t l = edge_lds_bytes(NB, EW, false);
+    const size_t l = pair_lds_bytes(NB, EW);
     if (first && last) hipLaunchKernelGGL((painn_pair_kernel<2 * NB, true, true, PREC, EW>), g, t, l, st, p);
     else if (first) hipLaunchKernelGGL((painn_pair_kernel<2 * NB, true, false, PREC, EW>), g, t, l, st, p);
     else if (last) hipLaunchKernelGGL((painn_pair_kernel<2 * NB, false, true, PREC, EW>), g, t, l, st, p);

@@ -202,7 +202,7 @@ hipError_t launch_noise(float* x, float sigma, uint64_t seed, long long traj0, i
                         int atoms_for_com /*0 = no COM removal*/, hipStream_t st);
 hipError_t launch_scale(float* y, const float* x, float a, long long n, hipStream_t st);                            // y = a*x
 hipError_t launch_selftest(float* out /*[64*16]*/, hipStream_t st);
-hipError_t launch_split_selftest(unsigned* out /*[1], zeroed*/, hipStream_t st);
+hipError_t launch_split_selftest(unsigned* out /*[2], zeroed: differing halves, subnormal-product mismatches*/, hipStream_t st);
 hipError_t launch_nan_check(const float* x, long long n, int* flag, hipStream_t st);
 
 // ---- Runge-Kutta pieces (ode_kernels.hip)

@@ -71,10 +71,17 @@ def child(batch, steps, precision, small):
         x0, cond = syn.molecule_coords(batch, A, seed=0), syn.ambient_cond(batch, A)
         grid = E._time_grid_numpy(0.0, 1.0, 1001)
         eng.reserve(batch)
-        eng.rollout(x0, cond, grid[:2], scheme="em", eps=0.01, seed=1, save_every=0)
+        def roll(g):                         # experiment variants may produce non-finite states (TI_E_NAN): the timing still counts
+            try:
+                return eng.rollout(x0, cond, g, scheme="em", eps=0.01, seed=1, save_every=0)[0]
+            except ti._lib.TiError as e:
+                if e.code != ti._lib.TI_E_NAN:
+                    raise
+                return np.full((1, 1), np.nan, np.float32)
+        roll(grid[:2])
         eng.profile(True)
         t0 = time.perf_counter()
-        out, _ = eng.rollout(x0, cond, grid[1:steps + 2], scheme="em", eps=0.01, seed=1, save_every=0)
+        out = roll(grid[1:steps + 2])
         dt = time.perf_counter() - t0
         eng.profile(False)
         prof = {k: eng.profile_read(k) for k in ("painn_edge", "painn_update", "painn_embed", "painn_readout")}
