@@ -175,17 +175,18 @@ def main():
         prof = {k: eng.profile_read(k) for k in ("painn_edge", "painn_update", "painn_embed", "painn_readout")}
         assert bool(torch.isfinite(out).all())
         parity = drift_rel_l2(ti, eng, flat, template) if rank == 0 and world == 1 and not args.no_parity else None
+        layout = eng.template_for(B)
         eng.close()
-        return dt, prof, parity
+        return dt, prof, parity, layout
 
-    elapsed, prof, parity = measure(args.precision)
+    elapsed, prof, parity, layout = measure(args.precision)
     n_edge, ms_edge = prof["painn_edge"]
     n_upd, ms_upd = prof["painn_update"]
     f32_leg = None
     if args.precision != "f32" and not args.no_f32_leg:
-        dt32, prof32, parity32 = measure("f32")
+        dt32, prof32, parity32, layout32 = measure("f32")
         f32_leg = {"value": world * B * args.steps / dt32, "ms_per_step": 1e3 * dt32 / args.steps,
-                   "edge_kernel_avg_ms": prof32["painn_edge"][1] / max(prof32["painn_edge"][0], 1),
+                   "edge_kernel_avg_ms": prof32["painn_edge"][1] / max(prof32["painn_edge"][0], 1), "edge_row_layout": layout32,
                    "edge_kernel_frac_of_f32_mfma_peak": B * E_M * FLOP_PER_EDGE_LAYER / (prof32["painn_edge"][1] / max(prof32["painn_edge"][0], 1) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         if parity32:
             f32_leg["drift_rel_l2"] = parity32
@@ -216,7 +217,7 @@ def main():
                        "trajectories_per_gpu": B, "atoms": A, "n_features": F, "score_layers": L, "scheme": "em", "eps": args.eps,
                        "sharding": f"dp{world} over independent trajectories, final RCCL all-gather of end states"},
             "whole_step_tflops": FLOP_PER_MOL_EVAL * B * args.steps * world / elapsed / 1e12,
-            "roofline": {"kernel": "painn_edge_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"kernel": "painn_pair_kernel (pair-major message kernel: filter branch once per atom pair)" if layout == "pair" else "painn_edge_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak if achieved else None, "traffic": traffic,
                          "peak_is": "dense fp16 MFMA (2.5 PF); the split path spends 3 fp16 products per algorithmic product, so its matrix-side ceiling is peak/3"
                                     if split else "f32 MFMA (157.3 TF)",

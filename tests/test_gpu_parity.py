@@ -191,12 +191,11 @@ def test_painn_large_batch_properties():
     # a slice of the batch evaluated on its own (group/tile padding does not leak): bit for bit with the same edge template;
     # a small batch alone switches to the latency template (other row blocking, same sums in another order)
     assert rel_l2(eng.drift(x[:131], 0.5, cond[:131]), b[:131]) < 2e-6
-    import os
-    os.environ["TI_TEMPLATE"] = "throughput"
-    try:
-        np.testing.assert_array_equal(eng.drift(x[:131], 0.5, cond[:131]), b[:131])
-    finally:
-        del os.environ["TI_TEMPLATE"]
+    # (131 molecules = 65.5 directed groups of two; the pair-major layout walks groups of four: 132)
+    for layout, n in (("throughput", 131), ("pair", 132)):
+        eng.set_template(layout)
+        np.testing.assert_array_equal(eng.drift(x[:n], 0.5, cond[:n]), eng.drift(x, 0.5, cond)[:n])
+    eng.set_template("auto")
     orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
     idx = np.r_[0:3, B - 3:B]
     assert rel_l2(b[idx], orc.drift(x[idx], 0.5, cond[idx])) < DRIFT_TOL

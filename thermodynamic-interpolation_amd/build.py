@@ -13,6 +13,11 @@ SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_
            "painn_pair_nb1.hip", "painn_pair_nb2.hip", "painn_pair_nb4.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
 HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", "painn_edge_kernel.hpp", "painn_pair_kernel.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# Per-source flags.  painn_edge_nb8.hip (F = 256, one wave per SIMD): hipcc (ROCm 7.2) spills 28 SGPRs of the one-accumulator message
+# kernel into lanes of a VGPR, and that build faults on the device in its first launch (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION,
+# profiles/r02h_f256_one_chain_fault.txt); the same source with the lane spills switched off allocates them to registers (no scratch) and
+# passes every stage at 1.6e-6 (profiles/r03e_f256_one_chain_no_lane_spill.txt).  DESIGN.md 3.4.
+EXTRA_FLAGS = {"painn_edge_nb8.hip": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]}
 
 
 def hipcc() -> str:
@@ -40,7 +45,7 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = False) -> str:
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(obj, [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]):
-            cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

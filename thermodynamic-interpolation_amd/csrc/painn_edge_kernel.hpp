@@ -58,11 +58,12 @@ __device__ __forceinline__ void acc_out(float* p, float v, bool first)
 __host__ __device__ constexpr int edge_superchunk(int NB, int WAVES, bool H16 = false) { return ((WAVES == 8 && NB == 4) ? 4 : 2) * (H16 && NB == 4 ? 2 : 1); }
 __host__ __device__ constexpr int edge_chunk4(int NB, bool H16) { return (H16 ? 128 : 256) * NB; }            // float4 per weight chunk
 // F = 32 in the storage mode: a 2-chunk superchunk (4 KB) is smaller than one 16-byte lane per thread of the 8-wave build
-// Does this (feature width, precision) run the one-accumulator split format (mfma_chain.hpp: Opnd1)?  TI_PREC_F16X2 up to F = 128.  The
-// F = 256 build of it (one wave per SIMD, operands partly in AGPRs) faulted on the device in the first GPU run and keeps the
-// two-accumulator format until that is understood; ti_api.hip packs the message streams accordingly.
+// Does this (feature width, precision) run the one-accumulator split format (mfma_chain.hpp: Opnd1)?  TI_PREC_F16X2 at every width;
+// ti_api.hip packs the message streams accordingly.  The F = 256 build (one wave per SIMD, operands partly in AGPRs) faulted on the
+// device (memory aperture violation in its first launch) when hipcc spilled SGPRs into VGPR lanes: painn_edge_nb8.hip is compiled
+// with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 (build.py), which removes the fault.
 #ifndef TI_ONE_CHAIN_MAX_NB
-#define TI_ONE_CHAIN_MAX_NB 4
+#define TI_ONE_CHAIN_MAX_NB 8
 #endif
 __host__ __device__ constexpr bool edge_one_chain(int NB, int PREC) { return PREC == 1 && NB <= TI_ONE_CHAIN_MAX_NB; }
 __host__ __device__ constexpr bool edge_build_exists(int NB, int WAVES, int PREC) { return !(PREC == 2 && NB == 1 && WAVES == 8); }
@@ -73,7 +74,6 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
     constexpr int F = 16 * NBK, NB = (F + 31) / 32, T = 64 * WAVES, CH4 = edge_chunk4(NB, H16);
     using A16 = r16::Act<NBK>;
     // split-fp16 path: the one-accumulator operand / weight format (mfma_chain.hpp: Opnd1; weights scaled per matrix, p.wscale)
-    // (F <= 128 only: edge_one_chain)
     constexpr bool ONE = edge_one_chain(NB, PREC);
     using OP = std::conditional_t<ONE, r16::Opnd1<NBK>, typename r16::OpSel<NBK, PREC>::type>;
     extern __shared__ f32x4 lds[];
@@ -100,6 +100,10 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
     const uint32_t* rows = p.rows + (size_t)(gi - mg * p.parts) * p.nblk * 16;
     const int32_t* slotnode = p.slotnode + (size_t)(gi - mg * p.parts) * p.nblk * 16;
 
+#ifdef TI_STAMPS      // diagnostic build only: (s_memtime, s_memrealtime) around the block loop of every wave -> in-kernel clock (MI355X guide, DVFS item 6)
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (p.stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     for (int blk = 0; blk < p.nblk; ++blk) {
         // ---- K1 geometry of this lane's row (the 4 quarters compute the same row)
         const uint32_t meta = rows[blk * 16 + j];
@@ -332,6 +336,13 @@ __global__ __launch_bounds__(64 * WAVES, (NBK <= 8 ? 2 * 4 / WAVES : 1)) void pa
         }
     }
     pipe.drain();
+#ifdef TI_STAMPS
+    if (p.stamps && lane == 0) {
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* c = p.stamps + 2048 + 2 * (size_t)gi_raw;
+        c[0] = clk1 - clk0; c[1] = rt1 - rt0;
+    }
+#endif
 }
 
 // edge kernel LDS: two superchunks of two weight chunks, per-wave edge_dir scratch (4 waves x 16 rows x 16 B), layer vectors

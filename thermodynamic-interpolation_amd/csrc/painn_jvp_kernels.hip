@@ -372,15 +372,26 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
                 out_pair(2, nbo, v0, v1, d0, d1);
                 emit(d0, d1, p.tdsacc + fo, F);
             }
-            if (!last) {   // de
+            if (!last) {   // de: te += d(de).  Every tangent edge row has ONE owner (this wave), so the update is a plain load / add / store
+                // instead of the 32 fire-and-forget atomic instructions per row block it used to be (more than half of this kernel's
+                // dword atomics).  Measured: the launch takes the same 46.9 ms either way (profiles/r03f_divergence_*): like the primal
+                // message kernel this one is bound by its serial per-wave timeline, not by L2's atomic rate.  The old rows are
+                // requested before the products and consumed behind them.
+                f32x4 o0 = Z4, o1 = Z4;
+                if (!first) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* ep = p.te + (trow0 + 4 * q + r) * F + fo;
+                        o0[r] = ep[0]; o1[r] = ep[16];
+                    }
+                }
                 f32x4 v0, v1, d0, d1;
                 out_pair(3, nbo, v0, v1, d0, d1);
+                if (group_ok) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* ep = p.te + (trow0 + 4 * q + r) * F + fo;
-                    if (group_ok) {
-                        if (first) { ep[0] = d0[r]; ep[16] = d1[r]; }
-                        else { add_noret(ep, d0[r]); add_noret(ep + 16, d1[r]); }
+                    for (int r = 0; r < 4; ++r) {
+                        float* ep = p.te + (trow0 + 4 * q + r) * F + fo;
+                        ep[0] = o0[r] + d0[r]; ep[16] = o1[r] + d1[r];
                     }
                 }
             }

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
     for (int i = threadIdx.x; i < EV::COUNT * F / 4; i += T)
         reinterpret_cast<f32x4*>(vec)[i] = reinterpret_cast<const f32x4*>(p.vecs)[i];
 #ifndef TI_PAIR_STAGGER
-#define TI_PAIR_STAGGER 1
+#define TI_PAIR_STAGGER 0
 #endif
     PipeDMA<NB, T, SC, CH4, WAVES == 8 && TI_PAIR_STAGGER, NBUF> pipe;        // 8 waves: SIMD partners half a phase apart (mfma_chain.hpp)
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
@@ -106,6 +106,29 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
         OP enc;
         f32x4* const enc_park = reinterpret_cast<f32x4*>(p.enc) + (brow0 / 16) * (sizeof(OP) / 16) * 64 + lane;
         f32x4* const geo_park = reinterpret_cast<f32x4*>(p.geo) + brow0 + j;
+#ifndef TI_PAIR_PREFETCH
+#define TI_PAIR_PREFETCH 0
+#endif
+        // L2 warm-up (measured: a LOSS, 32.3 -> 33.4 ms same box, profiles/r03d_*; off by default): the e rows of this block are first
+        // needed two hidden layers from here and the next block's parked encoding a whole block from here, both straight from HBM.  One
+        // dword per 128-byte line now (2 + 2 load instructions) turns the later 16-byte loads into L2 hits; the values are consumed (and so
+        // waited for) only where the real loads are.
+        float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
+        if (TI_PAIR_PREFETCH && !FIRST) {
+            constexpr int LPR = F * 4 / 128;                         // 128-byte lines per e row
+            const float* eb0 = p.e + erowA * F;                      // 32 rows (both directions) x LPR lines, 64 lanes per instruction
+#pragma unroll
+            for (int k = 0; k < (32 * LPR + 63) / 64; ++k) {
+                const int line = k * 64 + lane;
+                const float v = eb0[(size_t)(line < 32 * LPR ? line : 0) * 32];
+                if (k == 0) pf0 = v; else pf1 += v;
+            }
+            if (blk + 1 < p.nblk) {
+                const float* nb = reinterpret_cast<const float*>(reinterpret_cast<const f32x4*>(p.enc) + (brow0 / 16 + 1) * (sizeof(OP) / 16) * 64);
+#pragma unroll
+                for (int k = 0; k < (int)(sizeof(OP) * 64 / 128 + 63) / 64; ++k) pf2 += nb[(size_t)(k * 64 + lane) * 32];
+            }
+        }
         if constexpr (FIRST) {
             const float rx = p.x[nI * 3 + 0] - p.x[nJ * 3 + 0];
             const float ry = p.x[nI * 3 + 1] - p.x[nJ * 3 + 1];
@@ -165,6 +188,7 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 scA = inA.set_scaled(tA);
                 inB = inA; scB = scA;
             } else {
+                asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));      // the warm-up loads are waited for here, with the rows themselves
                 r16::load_set(tA, p.e + (erowA + j) * F, q);
                 r16::load_set(tB, p.e + (erowB + j) * F, q);
                 scA = inA.set_scaled(tA);                                    // e is an un-normalised stream: per-row 2^k
@@ -209,10 +233,22 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
 #pragma unroll
         for (int r = 0; r < 4; ++r) wfac[r] = (mi[r] & 1u) ? inv_out : 0.0f;
         // partial-sum rows of this lane row: direction A's sums belong to J slot q (row 4 + q of the block's eight), direction B's to I slot q
+#ifndef TI_PAIR_ACC_ATOMIC
+#define TI_PAIR_ACC_ATOMIC 1      // 1 (default, measured 29.4 vs 31.5 ms same box): per-atom sums straight into dsacc / dvacc / cacc with fire-and-forget
+                                  // atomics (first touch replaces), no reduction pass; 0: per-(block, slot) partial rows + pair_reduce_kernel
+#endif
         float* const part_blk = p.part + ((size_t)gi_ps * p.nblk + blk) * 8 * (7 * F);
-        const bool haveA = group_ok && p.slotnode[blk * 16 + 4 + q] >= 0, haveB = group_ok && p.slotnode[blk * 16 + q] >= 0;
+        const int snJ = p.slotnode[blk * 16 + 4 + q], snI = p.slotnode[blk * 16 + q];
+        const bool haveA = group_ok && snJ >= 0 && (!TI_PAIR_ACC_ATOMIC || gi * p.G + slot_mol(snJ) < p.B);
+        const bool haveB = group_ok && snI >= 0 && (!TI_PAIR_ACC_ATOMIC || gi * p.G + slot_mol(snI) < p.B);
         float* const partA = part_blk + (size_t)(4 + q) * (7 * F);
         float* const partB = part_blk + (size_t)q * (7 * F);
+        // atomic variant: the accumulator rows of the two destination atoms, laid out as three arrays (ds [F], dv [3F], c [3F] per node)
+        const long long qnA = (gi * p.G + slot_mol(snJ)) * p.A + (snJ & 255), qnB = (gi * p.G + slot_mol(snI)) * p.A + (snI & 255);
+        const bool qfA = (snJ & SLOT_FIRST_TOUCH) != 0, qfB = (snI & SLOT_FIRST_TOUCH) != 0;
+        auto acc_ptr = [&](long long node, int off) {          // off as for the partial rows: ds 0.., dv F.., c 4F..
+            return off < F ? p.dsacc + node * F + off : off < 4 * F ? p.dvacc + node * 3 * F + (off - F) : p.cacc + node * 3 * F + (off - 4 * F);
+        };
         const long long nIq = node_of(prow_molI(mi[0]), prow_atomI(mi[0]));      // source of direction A for all four rows of this lane
 
         // (phi_c + b) of both directions times the shared (w_c + b) for output slice c (0 gates, 1 scale_edge_dir, 2 ds, 3 de,
@@ -237,12 +273,14 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
         // off: offset of the quantity inside a partial row (ds 0, dv (1 + c) F, c (4 + c) F) plus the lane's feature
         auto emitA = [&](const f32x4& v0, const f32x4& v1, int off) {
             const float z0 = sumA(v0), z1 = sumA(v1);
-            if (haveA) { partA[off] = z0; partA[off + 16] = z1; }
+            if (TI_PAIR_ACC_ATOMIC) { if (haveA) { float* d = acc_ptr(qnA, off); acc_out(d, z0, qfA); acc_out(d + 16, z1, qfA); } }
+            else if (haveA) { partA[off] = z0; partA[off + 16] = z1; }
         };
         // direction B: the four registers of a lane are the J slots of ONE destination I[q]
         auto emitB = [&](const f32x4& v0, const f32x4& v1, int off) {
             const float z0 = (v0[0] + v0[1]) + (v0[2] + v0[3]), z1 = (v1[0] + v1[1]) + (v1[2] + v1[3]);
-            if (haveB) { partB[off] = z0; partB[off + 16] = z1; }
+            if (TI_PAIR_ACC_ATOMIC) { if (haveB) { float* d = acc_ptr(qnB, off); acc_out(d, z0, qfB); acc_out(d + 16, z1, qfB); } }
+            else if (haveB) { partB[off] = z0; partB[off + 16] = z1; }
         };
         const float wrow = (meta & 1u) ? inv_out : 0.0f;                 // the same row factor in the row layout (lane (j, q): row j)
 
@@ -350,7 +388,7 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
 #ifdef TI_STAMPS
     if (p.stamps && lane == 0) {          // whole-loop clock pair of every wave: [4 * WAVES * STAMP_SLOTS + 2 * wave id ...]
         const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* c = p.stamps + (size_t)4 * WAVES * STAMP_SLOTS + 2 * (size_t)gi_raw;
+        unsigned long long* c = p.stamps + 2048 + 2 * (size_t)gi_raw;
         c[0] = clk1 - clk0; c[1] = rt1 - rt0;
     }
 #endif
@@ -391,6 +429,7 @@ static void launch_pair_p(bool first, bool last, const EdgeParams& p, hipStream_
     else hipLaunchKernelGGL((painn_pair_kernel<2 * NB, false, false, PREC, EW>), g, t, l, st, p);
     }
 }
+static bool pair_writes_partials() { return !TI_PAIR_ACC_ATOMIC; }
 template <int NB>
 static hipError_t launch_pair_nb(bool first, bool last, int prec, const EdgeParams& p, hipStream_t st)
 {

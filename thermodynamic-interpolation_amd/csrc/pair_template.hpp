@@ -44,7 +44,10 @@ struct Blk {
 
 // src / dst / etype: the E directed edges of ONE molecule (A <= 32 atoms).  Returns false (no pair template) when the directed graph
 // is not the symmetric closure of an undirected one with one type per pair.
-inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t* dst, const int32_t* etype, PairTemplate& out)
+// first_touch: mark (PAIR_SLOT_FIRST_TOUCH), per atom, the first slot that holds it in walk order -- inside a block the J slots
+// (direction A) before the I slots (direction B): the order the atomic variant of the kernel issues its accumulator updates in.
+constexpr int32_t PAIR_SLOT_FIRST_TOUCH = 1 << 30;      // == ti::SLOT_FIRST_TOUCH (ti_internal.hpp)
+inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t* dst, const int32_t* etype, PairTemplate& out, bool first_touch = false)
 {
     using pair_detail::Blk;
     if (E <= 0 || (E & 1) || A > 32) return false;
@@ -149,7 +152,7 @@ inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t*
     out.G = G; out.nblk = nblk;
     out.rows.assign((size_t)nblk * RB, 0u); out.slotnode.assign((size_t)nblk * RB, -1);
     out.pair_pos.assign((size_t)G * A * A, -1);
-    std::vector<char> done((size_t)G * A * A, 0);
+    std::vector<char> done((size_t)G * A * A, 0), touched((size_t)G * 32, 0);
     size_t n_valid = 0;
     for (int bi = 0; bi < nblk; ++bi) {
         const Blk& b = best[bi];
@@ -173,10 +176,14 @@ inline bool build_pair_template(int A, int E, const int32_t* src, const int32_t*
                     out.pair_pos[((size_t)m * A + j) * A + i] = (bi * 2 + 1) * RB + 4 * a + c;       // direction B: J[c] -> I[a]
                 }
             }
-        for (int k = 0; k < 4; ++k) {
-            if (b.I[k] >= 0) out.slotnode[(size_t)bi * RB + k] = ((b.I[k] / 32) << 8) | (b.I[k] % 32);
-            if (b.J[k] >= 0) out.slotnode[(size_t)bi * RB + 4 + k] = ((b.J[k] / 32) << 8) | (b.J[k] % 32);
-        }
+        for (int side = 0; side < 2; ++side)               // J slots first (see first_touch above)
+            for (int k = 0; k < 4; ++k) {
+                const int key = side ? b.I[k] : b.J[k];
+                if (key < 0) continue;
+                const int32_t first = (first_touch && !touched[key]) ? PAIR_SLOT_FIRST_TOUCH : 0;
+                touched[key] = 1;
+                out.slotnode[(size_t)bi * RB + (side ? k : 4 + k)] = first | ((key / 32) << 8) | (key % 32);
+            }
     }
     // partial-sum lists per atom: slot k of block bi (k < 4: the I slots = direction B's destinations; k >= 4: the J slots = direction
     // A's), in walk order -- the order the reduction adds them in

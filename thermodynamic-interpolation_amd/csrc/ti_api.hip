@@ -363,7 +363,7 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
 static bool build_pair_template(ti_handle* h, const int32_t* src, const int32_t* dst, const int32_t* etype)
 {
     ti::PairTemplate pt;
-    if (!ti::build_pair_template(h->d.n_atoms, h->d.n_edges, src, dst, etype, pt)) return false;
+    if (!ti::build_pair_template(h->d.n_atoms, h->d.n_edges, src, dst, etype, pt, h->first_touch && !pair_uses_partials())) return false;
     ti_handle::Tpl& T = h->tpl[2];
     T.G = pt.G; T.P = 1; T.nblk = pt.nblk; T.max_slots = 4;
     T.rows.upload(pt.rows); T.slotnode.upload(pt.slotnode);
@@ -590,7 +590,7 @@ void ensure_painn_ws(ti_handle* h, long long B)
     // parked geometry of a drift evaluation (painn_edge_kernel.hpp): the encoding operand of every edge row (as many bytes as e) and edge_dir
     h->enc.alloc((edge_rows_for(h, B) * F + se - 1) / se); h->geo.alloc(edge_rows_for(h, B) * 4);
     h->divb.alloc(B); h->div2.alloc(B); h->dl.alloc(B); h->dlscaled.alloc(B);
-    if (h->has_pair) h->part.alloc((size_t)((B + h->tpl[2].G - 1) / h->tpl[2].G) * h->tpl[2].nblk * 8 * 7 * F);
+    if (h->has_pair && pair_uses_partials()) h->part.alloc((size_t)((B + h->tpl[2].G - 1) / h->tpl[2].G) * h->tpl[2].nblk * 8 * 7 * F);
     h->cap = B;
 }
 
@@ -724,36 +724,46 @@ void painn_drift_dev(ti_handle* h, const float* x_dev, float t, const float* con
                 for (int i = 0; i < 6; ++i) p.wscale[i] = h->edge_scale[(size_t)l * 6 + i];
             }
             Timed tm(h, TI_KERNEL_PAINN_EDGE);
+#ifdef TI_STAMPS      // diagnostic build only: stamps of layer 2's launch, printed to stderr
+            static DevBuf<unsigned long long> stamp_buf;
+            const size_t n_st = 2048 + 2 * (size_t)groups + 16;
+            if (l == 2 && std::getenv("TI_STAMPS_DUMP")) { if (stamp_buf.n < n_st) stamp_buf.alloc(n_st); HIP_CHECK(hipMemsetAsync(stamp_buf.p, 0, n_st * 8, st)); p.stamps = stamp_buf.p; }
+            auto dump_stamps = [&]() {
+                if (!p.stamps) return;
+                std::vector<unsigned long long> hs(n_st);
+                HIP_CHECK(hipStreamSynchronize(st));
+                HIP_CHECK(hipMemcpy(hs.data(), stamp_buf.p, n_st * 8, hipMemcpyDeviceToHost));
+                for (int w = 0; w < 32; ++w) {
+                    if (!hs[(size_t)w * 64 + 1]) continue;
+                    std::fprintf(stderr, "STAMP %d:", w);
+                    for (int k = 1; k < 64 && hs[(size_t)w * 64 + k]; ++k) std::fprintf(stderr, " %llu", hs[(size_t)w * 64 + k] - hs[(size_t)w * 64 + k - 1]);
+                    std::fprintf(stderr, "\n");
+                }
+                std::vector<double> clk;
+                for (long long g2 = 0; g2 < groups; ++g2) { const auto c = hs[2048 + 2 * g2], r = hs[2048 + 2 * g2 + 1]; if (r) clk.push_back(100e6 * (double)c / (double)r); }
+                std::sort(clk.begin(), clk.end());
+                if (!clk.empty()) std::fprintf(stderr, "INKERNEL_CLOCK_GHZ median %.4f  p10 %.4f  p90 %.4f  waves %zu  layout %d  precision %d\n", clk[clk.size() / 2] / 1e9,
+                                               clk[clk.size() / 10] / 1e9, clk[clk.size() * 9 / 10] / 1e9, clk.size(), h->active, prec);
+            };
+#endif
             if (h->active == 2) {
                 p.part = h->part.p;
-#ifdef TI_STAMPS      // diagnostic build only: stamps of layer 2's launch, printed to stderr (tools/stamps.py reads them)
-                static DevBuf<unsigned long long> stamp_buf;
-                const size_t n_st = 4 * 8 * 64 + 2 * (size_t)groups + 16;
-                if (l == 2 && std::getenv("TI_STAMPS_DUMP")) { if (stamp_buf.n < n_st) stamp_buf.alloc(n_st); HIP_CHECK(hipMemsetAsync(stamp_buf.p, 0, n_st * 8, st)); p.stamps = stamp_buf.p; }
-#endif
                 HIP_CHECK(launch_pair(NB, l == 0, l == L - 1, prec, p, st));
 #ifdef TI_STAMPS
-                if (p.stamps) {
-                    std::vector<unsigned long long> hs(n_st);
-                    HIP_CHECK(hipStreamSynchronize(st));
-                    HIP_CHECK(hipMemcpy(hs.data(), stamp_buf.p, n_st * 8, hipMemcpyDeviceToHost));
-                    const int EWv = groups >= 2048 && prec == 1 ? 8 : 4;
-                    for (int w = 0; w < 4 * EWv; ++w) {
-                        std::fprintf(stderr, "STAMP %d:", w);
-                        for (int k = 1; k < 64 && hs[(size_t)w * 64 + k]; ++k) std::fprintf(stderr, " %llu", hs[(size_t)w * 64 + k] - hs[(size_t)w * 64 + k - 1]);
-                        std::fprintf(stderr, "\n");
-                    }
-                    std::vector<double> clk;
-                    for (long long g2 = 0; g2 < groups; ++g2) { const auto c = hs[(size_t)4 * EWv * 64 + 2 * g2], r = hs[(size_t)4 * EWv * 64 + 2 * g2 + 1]; if (r) clk.push_back(100e6 * (double)c / (double)r); }
-                    std::sort(clk.begin(), clk.end());
-                    if (!clk.empty()) std::fprintf(stderr, "INKERNEL_CLOCK_GHZ median %.4f  p10 %.4f  p90 %.4f  waves %zu\n", clk[clk.size() / 2] / 1e9, clk[clk.size() / 10] / 1e9, clk[clk.size() * 9 / 10] / 1e9, clk.size());
-                }
+                dump_stamps();
 #endif
+                if (pair_uses_partials()) {
                 PairReduceParams r{};
                 r.part = h->part.p; r.plist = h->pair_plist.p; r.kmax = h->pair_kmax; r.G = h->G; r.A = A; r.F = F; r.nblk = h->nblk;
                 r.has_c = l > 0; r.B = B; r.dsacc = h->dsacc.p; r.dvacc = h->dvacc.p; r.cacc = h->cacc.p;
                 HIP_CHECK(launch_pair_reduce(r, st));
-            } else HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
+                }
+            } else {
+                HIP_CHECK(launch_edge(NB, l == 0, l == L - 1, prec, p, st));
+#ifdef TI_STAMPS
+                dump_stamps();
+#endif
+            }
         }
         if (h->tap == 1 + 2 * l) return;
         if (jr) {

@@ -124,6 +124,7 @@ bool edge_uses_one_chain(int NB, int prec);      // message kernel on the one-ac
 // pair-major message kernel (painn_pair_kernel.hpp): same EdgeParams, rows / slotnode of the pair template, same weight stream
 hipError_t launch_pair(int NB, bool first, bool last, int prec, const EdgeParams& p, hipStream_t st);
 bool pair_kernel_exists(int NB, int prec);
+bool pair_uses_partials();          // the pair kernel writes per-(block, slot) partial sums that launch_pair_reduce adds up (else: atomics, first touch)
 hipError_t launch_update(int NB, bool has_next, int prec, const UpdateParams& p, hipStream_t st);
 hipError_t launch_readout(int NB, int prec, const ReadoutParams& p, hipStream_t st);
 hipError_t configure_painn_kernels(int NB);     // dynamic-LDS attributes

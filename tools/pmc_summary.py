@@ -32,13 +32,13 @@ for k, d in C.items():
 import json, os
 tot = {"r": 0.0, "w": 0.0, "n": 0}
 for k, d in C.items():
-    if k.startswith("painn_edge_kernel") and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+    if k.startswith(("painn_edge_kernel", "painn_pair_kernel")) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:      # the message kernel, either layout
         n = len(d["FETCH_SIZE"])
         tot["r"] += 2 * sum(d["FETCH_SIZE"]) * 1024; tot["w"] += sum(d["WRITE_SIZE"]) * 1024; tot["n"] += n
 if tot["n"] and os.environ.get("PMC_BATCH"):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_sources_sha
-    json.dump({"kernel": "painn_edge_kernel", "kernel_sources_sha": kernel_sources_sha(), "batch": int(os.environ["PMC_BATCH"]), "precision": os.environ.get("PMC_PRECISION", "f16x2"),
+    json.dump({"kernel": "message kernel (painn_pair_kernel / painn_edge_kernel)", "kernel_sources_sha": kernel_sources_sha(), "batch": int(os.environ["PMC_BATCH"]), "precision": os.environ.get("PMC_PRECISION", "f16x2"),
                "read_bytes_per_launch": tot["r"] / tot["n"], "write_bytes_per_launch": tot["w"] / tot["n"], "launches_measured": tot["n"],
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE (KB) doubled for 16-byte streaming reads (MI355X guide)",
                "source": f"gpurun_out/pmc_{tag}_fetch, pmc_{tag}_write"}, open("profiles/pmc_edge_traffic.json", "w"), indent=1)
