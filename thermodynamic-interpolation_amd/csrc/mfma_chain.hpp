@@ -50,6 +50,16 @@ __device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) 
 __device__ __forceinline__ void lane_swap16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lane_swap32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 
+// XCD-aware workgroup order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its own
+// 4 MiB L2; MI355X guide), so workgroups that read the SAME data -- the 54 seed directions of one primal molecule group in the
+// tangent kernels -- should be neighbours on ONE XCD, not neighbours in blockIdx: logical index = (blocks of the XCDs before mine) +
+// (my rank on my XCD).  A bijection of [0, n); purely a speed matter (no correctness depends on the placement).
+__device__ __forceinline__ long long xcd_swizzle(unsigned b, unsigned n)
+{
+    const unsigned q = n >> 3, r = n & 7u, x = b & 7u, i = b >> 3;
+    return (x < r ? (long long)x * (q + 1) : (long long)r * (q + 1) + (long long)(x - r) * q) + i;
+}
+
 // v + (the value of the lane 32 away), in every lane
 // 1 / sqrt(x) for the LayerNorm scale: v_rsq_f32 (1 ulp) and one Newton step -- 5 instructions, within an ulp of the correctly rounded
 // quotient; `1.0f / sqrtf(x)` compiles to ~25 (IEEE square root + IEEE division fix-ups) once per row and LayerNorm.

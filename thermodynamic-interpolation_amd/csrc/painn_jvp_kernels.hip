@@ -231,7 +231,13 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
     PipeDMA<NB, T, 2> pipe;
     pipe.init(reinterpret_cast<const f32x4*>(p.stream), p.nch, lds, wave, lane);
 
-    const long long gi_raw = (long long)blockIdx.x * WAVES + wave;                 // virtual group
+#ifndef TI_JVP_XCD
+#define TI_JVP_XCD 1
+#endif
+    // virtual group.  The D directions of a primal group (consecutive virtual groups) read the same primal-pass rows (wq, st: 154 KB per
+    // row block at F = 128), the same P / v / e rows; dealt round-robin over the XCDs, every L2 fetched them again from HBM (140 GB
+    // read per launch, profiles/r03f_divergence_pmc_summary.txt): neighbours in the logical order share an XCD instead.
+    const long long gi_raw = (TI_JVP_XCD ? xcd_swizzle(blockIdx.x, gridDim.x) : (long long)blockIdx.x) * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
     // gi = (molecule group * D + direction) * P + part
