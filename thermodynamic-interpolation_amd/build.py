@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libti_hip.so")
 SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_nb2.hip", "painn_edge_nb4.hip", "painn_edge_nb8.hip",
            "painn_pair_nb1.hip", "painn_pair_nb2.hip", "painn_pair_nb4.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
-HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", "painn_edge_kernel.hpp", "painn_pair_kernel.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
+HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", "painn_edge_kernel.hpp", "painn_pair_kernel.hpp", "pair_template.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Per-source flags.  painn_edge_nb8.hip (F = 256, one wave per SIMD): hipcc (ROCm 7.2) spills 28 SGPRs of the one-accumulator message
 # kernel into lanes of a VGPR, and that build faults on the device in its first launch (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION,

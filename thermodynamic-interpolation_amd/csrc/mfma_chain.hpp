@@ -170,12 +170,8 @@ struct PipeDMA {
     int nsup, idx, ahead, buf, sub, wave, lane;       // idx: superchunk being consumed, ahead: the next one to request, buf = idx % NBUF
     bool defer, pending;                    // STAGGER: this wave closes superchunks lazily / a close is outstanding
 
-#ifndef TI_EXP_KNOB
-#define TI_EXP_KNOB 0     // experiment builds only: 1 no LayerNorm/SiLU arithmetic, 2 no workgroup barrier, 4 no weight DMA after init
-#endif
     __device__ __forceinline__ void dma(const f32x4* src, f32x4* dst) const
     {
-        if ((TI_EXP_KNOB & 4) && idx + sub + ahead != 0) return;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int o = k * T + wave * 64;                 // wave-uniform LDS base; lane i lands at base + 16*i bytes
@@ -200,12 +196,8 @@ struct PipeDMA {
     }
     __device__ __forceinline__ void close()
     {
-#ifdef TI_EXP_VMCNT       // experiment builds only: an (incorrect) lax wait, to price the in-order vmcnt drain of older atomics
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TI_EXP_VMCNT) : "memory");
-#else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PER) : "memory");
-#endif
-        if (!(TI_EXP_KNOB & 2)) __syncthreads();
+        __syncthreads();
     }
     // Call once at the very end of a kernel: the last release() has a prefetch in flight that nobody will consume, and an
     // LDS-DMA still in flight when the workgroup retires lands in LDS that may already belong to the next workgroup.
@@ -492,9 +484,6 @@ __device__ __forceinline__ void load_set(Act<NBK>& a, const float* p, int q)
 template <int NBK>
 __device__ __forceinline__ void ln_silu(Act<NBK>& a, const float* gamma, const float* beta, int q, float eps = 1e-5f)
 {
-#if defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 1)
-    return;
-#endif
     constexpr float invF = 1.0f / (16.0f * NBK);
     float sum = 0.f;
 #pragma unroll
@@ -660,11 +649,7 @@ __device__ __forceinline__ void posenc_dual(Act<NBK>& a, Act<NBK>& da, float x_o
 // on the host (pack_chunk16_split) with the same k-slot order; a chunk is still 16 KB at F = 128.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-#if defined(TI_EXP_NOMFMA)      // experiment builds only: everything but the fp16 matrix products (and the fragment reads that feed only them)
-__device__ __forceinline__ f32x4 mfma16h(h8 a, h8 b, f32x4 c) { c[0] += (float)a[0] + (float)b[0]; return c; }
-#else
 __device__ __forceinline__ f32x4 mfma16h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-#endif
 
 // exact reciprocal of a power of two (the row scales of Opnd::set_scaled)
 __device__ __forceinline__ float pow2_inverse(float s) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, s)); }
@@ -904,18 +889,12 @@ __device__ __forceinline__ void gemm_split_chunk1(f32x4& acc0, f32x4& acc1, cons
     for (int s = 0; s < AH; ++s) { fh[s] = wl[(2 * s) * 64 + lane]; fl[s] = wl[(2 * s + 1) * 64 + lane]; }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-#if !(defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8))
         if (s + AH < STEPS) {
             fh[(s + AH) % (AH + 1)] = wl[(2 * (s + AH)) * 64 + lane];
             fl[(s + AH) % (AH + 1)] = wl[(2 * (s + AH) + 1) * 64 + lane];
         }
-#endif
         __builtin_amdgcn_sched_barrier(0x16);
-#if defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8)      // experiment: one fragment pair per chunk (prices the LDS fragment reads)
-        const h8 wh = fh[0], wlo = fl[0];
-#else
         const h8 wh = fh[s % (AH + 1)], wlo = fl[s % (AH + 1)];
-#endif
         const int m = s % KS;
         f32x4& acc = s < KS ? acc0 : acc1;
         if (FLIP) { acc = mfma16h(in.hi[m], wh, acc); acc = mfma16h(in.lo[m], wh, acc); acc = mfma16h(in.hi[m], wlo, acc); }
@@ -940,18 +919,12 @@ __device__ __forceinline__ void gemm_split_chunk1_x2(f32x4& a0, f32x4& a1, f32x4
     for (int s = 0; s < AH; ++s) { fh[s] = wl[(2 * s) * 64 + lane]; fl[s] = wl[(2 * s + 1) * 64 + lane]; }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-#if !(defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8))
         if (s + AH < STEPS) {
             fh[(s + AH) % (AH + 1)] = wl[(2 * (s + AH)) * 64 + lane];
             fl[(s + AH) % (AH + 1)] = wl[(2 * (s + AH) + 1) * 64 + lane];
         }
-#endif
         __builtin_amdgcn_sched_barrier(0x16);
-#if defined(TI_EXP_KNOB) && (TI_EXP_KNOB & 8)
-        const h8 wh = fh[0], wlo = fl[0];
-#else
         const h8 wh = fh[s % (AH + 1)], wlo = fl[s % (AH + 1)];
-#endif
         const int m = s % KS;
         f32x4& accA = s < KS ? a0 : a1;
         f32x4& accB = s < KS ? b0 : b1;

@@ -26,19 +26,11 @@ struct EV {
 // Fire-and-forget fp32 add (global_atomic_add_f32, no return): nothing waits for the memory round trip.  Every
 // accumulator element starts at zero and is only ever added to by the one wave that owns the molecule, in program
 // order (an atom's <= 31 incoming edges span at most three 16-row blocks of that wave).
-#ifdef TI_EXP_NOATOM      // experiment builds only (tools/variant_bench.py): the accumulator traffic switched off at run time, values kept alive
-static __device__ bool ti_exp_never;      // never set
-__device__ __forceinline__ void add_noret(float* p, float v) { if (ti_exp_never) unsafeAtomicAdd(p, v); }
-#else
 __device__ __forceinline__ void add_noret(float* p, float v) { unsafeAtomicAdd(p, v); }
-#endif
 // accumulator update: a fire-and-forget atomic either way -- exchange on the first touch, add afterwards -- so that the later adds of the
 // same wave are ordered behind the replacement at L2 (a plain store takes another path)
 __device__ __forceinline__ void acc_out(float* p, float v, bool first)
 {
-#ifdef TI_EXP_NOATOM
-    if (!ti_exp_never) return;
-#endif
     if (first) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else unsafeAtomicAdd(p, v);
 }

@@ -68,14 +68,8 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
     const long long gi_raw = (long long)blockIdx.x * WAVES + wave;
     const bool group_ok = gi_raw < p.n_groups;
     const long long gi = group_ok ? gi_raw : p.n_groups - 1;
-#ifndef TI_EXP_MEM
-#define TI_EXP_MEM 0      // experiment builds only (tools/variant_bench.py): fold addresses onto a few groups so that the traffic stays in L2
-#endif
-    // bit 0: partial-sum stores, bit 1: e stores, bit 2: P / v / x gathers, bit 3: e / enc / geo loads
-    const long long gi_ps = (TI_EXP_MEM & 1) ? (gi & 7) : gi, gi_es = (TI_EXP_MEM & 2) ? (gi & 7) : gi;
-    const long long gi_g = (TI_EXP_MEM & 4) ? (gi & 7) : gi, gi_el = (TI_EXP_MEM & 8) ? (gi & 7) : gi;
     auto node_of = [&](int mol_local, int atom) {
-        long long m = gi_g * p.G + mol_local;
+        long long m = gi * p.G + mol_local;
         m = m < p.B ? m : p.B - 1;
         return m * p.A + atom;
     };
@@ -100,35 +94,11 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
         // ---- K1 geometry of this lane's pair row (the 4 quarters compute the same row); direction A: r = x[I] - x[J]
         const uint32_t meta = p.rows[blk * 16 + j];
         const long long nI = node_of(prow_molI(meta), prow_atomI(meta)), nJ = node_of(prow_molJ(meta), prow_atomJ(meta));
-        const size_t brow0 = ((size_t)gi_el * p.nblk + blk) * 16;       // pair rows: parked encoding / edge_dir
+        const size_t brow0 = ((size_t)gi * p.nblk + blk) * 16;       // pair rows: parked encoding / edge_dir
         const size_t erowA = brow0 * 2, erowB = erowA + 16;             // e rows of the two directions
-        const size_t srowA = ((size_t)gi_es * p.nblk + blk) * 32, srowB = srowA + 16;      // (the same rows: where e is stored)
         OP enc;
         f32x4* const enc_park = reinterpret_cast<f32x4*>(p.enc) + (brow0 / 16) * (sizeof(OP) / 16) * 64 + lane;
         f32x4* const geo_park = reinterpret_cast<f32x4*>(p.geo) + brow0 + j;
-#ifndef TI_PAIR_PREFETCH
-#define TI_PAIR_PREFETCH 0
-#endif
-        // L2 warm-up (measured: a LOSS, 32.3 -> 33.4 ms same box, profiles/r03d_*; off by default): the e rows of this block are first
-        // needed two hidden layers from here and the next block's parked encoding a whole block from here, both straight from HBM.  One
-        // dword per 128-byte line now (2 + 2 load instructions) turns the later 16-byte loads into L2 hits; the values are consumed (and so
-        // waited for) only where the real loads are.
-        float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
-        if (TI_PAIR_PREFETCH && !FIRST) {
-            constexpr int LPR = F * 4 / 128;                         // 128-byte lines per e row
-            const float* eb0 = p.e + erowA * F;                      // 32 rows (both directions) x LPR lines, 64 lanes per instruction
-#pragma unroll
-            for (int k = 0; k < (32 * LPR + 63) / 64; ++k) {
-                const int line = k * 64 + lane;
-                const float v = eb0[(size_t)(line < 32 * LPR ? line : 0) * 32];
-                if (k == 0) pf0 = v; else pf1 += v;
-            }
-            if (blk + 1 < p.nblk) {
-                const float* nb = reinterpret_cast<const float*>(reinterpret_cast<const f32x4*>(p.enc) + (brow0 / 16 + 1) * (sizeof(OP) / 16) * 64);
-#pragma unroll
-                for (int k = 0; k < (int)(sizeof(OP) * 64 / 128 + 63) / 64; ++k) pf2 += nb[(size_t)(k * 64 + lane) * 32];
-            }
-        }
         if constexpr (FIRST) {
             const float rx = p.x[nI * 3 + 0] - p.x[nJ * 3 + 0];
             const float ry = p.x[nI * 3 + 1] - p.x[nJ * 3 + 1];
@@ -188,7 +158,6 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 scA = inA.set_scaled(tA);
                 inB = inA; scB = scA;
             } else {
-                asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));      // the warm-up loads are waited for here, with the rows themselves
                 r16::load_set(tA, p.e + (erowA + j) * F, q);
                 r16::load_set(tB, p.e + (erowB + j) * F, q);
                 scA = inA.set_scaled(tA);                                    // e is an un-normalised stream: per-row 2^k
@@ -237,17 +206,17 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
 #define TI_PAIR_ACC_ATOMIC 1      // 1 (default, measured 29.4 vs 31.5 ms same box): per-atom sums straight into dsacc / dvacc / cacc with fire-and-forget
                                   // atomics (first touch replaces), no reduction pass; 0: per-(block, slot) partial rows + pair_reduce_kernel
 #endif
-        float* const part_blk = p.part + ((size_t)gi_ps * p.nblk + blk) * 8 * (7 * F);
+        float* const part_blk = p.part + ((size_t)gi * p.nblk + blk) * 8 * (7 * F);
         const int snJ = p.slotnode[blk * 16 + 4 + q], snI = p.slotnode[blk * 16 + q];
         const bool haveA = group_ok && snJ >= 0 && (!TI_PAIR_ACC_ATOMIC || gi * p.G + slot_mol(snJ) < p.B);
         const bool haveB = group_ok && snI >= 0 && (!TI_PAIR_ACC_ATOMIC || gi * p.G + slot_mol(snI) < p.B);
         float* const partA = part_blk + (size_t)(4 + q) * (7 * F);
         float* const partB = part_blk + (size_t)q * (7 * F);
         // atomic variant: the accumulator rows of the two destination atoms, laid out as three arrays (ds [F], dv [3F], c [3F] per node)
-        const long long qnA = (gi * p.G + slot_mol(snJ)) * p.A + (snJ & 255), qnB = (gi * p.G + slot_mol(snI)) * p.A + (snI & 255);
+        const int qnA = (int)((gi * p.G + slot_mol(snJ)) * p.A) + (snJ & 255), qnB = (int)((gi * p.G + slot_mol(snI)) * p.A) + (snI & 255);
         const bool qfA = (snJ & SLOT_FIRST_TOUCH) != 0, qfB = (snI & SLOT_FIRST_TOUCH) != 0;
-        auto acc_ptr = [&](long long node, int off) {          // off as for the partial rows: ds 0.., dv F.., c 4F..
-            return off < F ? p.dsacc + node * F + off : off < 4 * F ? p.dvacc + node * 3 * F + (off - F) : p.cacc + node * 3 * F + (off - 4 * F);
+        auto acc_ptr = [&](int node, int off) {                // off as for the partial rows: ds 0.., dv F.., c 4F..   (node < 2^31 / (3 F))
+            return off < F ? p.dsacc + (size_t)node * F + off : off < 4 * F ? p.dvacc + (size_t)node * 3 * F + (off - F) : p.cacc + (size_t)node * 3 * F + (off - 4 * F);
         };
         const long long nIq = node_of(prow_molI(mi[0]), prow_atomI(mi[0]));      // source of direction A for all four rows of this lane
 
@@ -319,10 +288,8 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                 pipe.release();
                 w0 *= wrow; w1 *= wrow;
                 if (group_ok) {
-                    float* const sa = p.e + (srowA + j) * F;
-                    float* const sb = p.e + (srowB + j) * F;
-                    r16::store_block(sa, 2 * nbo, q, oA0 + a0 * w0); r16::store_block(sa, 2 * nbo + 1, q, oA1 + a1 * w1);
-                    r16::store_block(sb, 2 * nbo, q, oB0 + b0 * w0); r16::store_block(sb, 2 * nbo + 1, q, oB1 + b1 * w1);
+                    r16::store_block(ea, 2 * nbo, q, oA0 + a0 * w0); r16::store_block(ea, 2 * nbo + 1, q, oA1 + a1 * w1);
+                    r16::store_block(eb, 2 * nbo, q, oB0 + b0 * w0); r16::store_block(eb, 2 * nbo + 1, q, oB1 + b1 * w1);
                 }
             }
             TI_STAMP();
