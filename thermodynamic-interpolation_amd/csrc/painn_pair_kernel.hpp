@@ -14,13 +14,13 @@
 //     and J slots r = 0..3.  Direction B (dst = I[q]) is an in-lane sum of the four registers; direction A (dst = J[r]) is the sum over
 //     the four lane rows, two v_permlane swap levels that leave slot q' in lane row q'.  Rows of pairs that do not exist are zeroed
 //     through the shared w factor (which also carries 1 / (S_phi S_w) of the one-accumulator format).
-//   * NO ATOMICS.  The directed kernel adds its per-atom sums and `e += de` with fire-and-forget float atomics; measured
-//     (profiles/r03a_atomics_experiment.txt), those dword atomics -- ~1 per L2 channel and clock, 4.9e9 per launch -- are 13.6 of its
-//     31.3 ms, and a pair-major kernel built the same way (8.3e9 of them: every slot of a 4 x 4 tile holds only four rows) sat at 30.0 ms
-//     against 12.0 ms without them.  Here every (block, slot) writes its partial sum of ds / dv / c with plain stores into its own row
-//     of a partial-sum buffer (`part`), and `pair_reduce_kernel` adds each atom's rows in walk order (ti_internal.hpp; deterministic,
-//     nothing to zero); the edge state is updated in the ROW layout (the de slice with the operands the other way round, like the fp16
-//     storage mode of the directed kernel): each e row has one owner, so e += de is a 16-byte load and store per lane.
+//   * Per-atom sums (ds / dv / c): one wave owns a molecule group and walks its blocks in order, so the sums of a (block, slot) go to the
+//     atom's accumulator row with fire-and-forget float atomics, the first touch of a launch replacing the stale contents (acc_out,
+//     painn_edge_kernel.hpp) -- no reduction pass, nothing to zero (TI_PAIR_ACC_ATOMIC = 1, the default: 29.4 ms against 31.5 ms, same
+//     box, for the alternative that is kept behind TI_PAIR_ACC_ATOMIC = 0: per-(block, slot) partial rows with plain stores +
+//     `pair_reduce_kernel`, profiles/r03e_*).  The edge state is updated in the ROW layout (the de slice with the operands the other
+//     way round, like the fp16 storage mode of the directed kernel): each e row has one owner, so e += de is a 16-byte load and store
+//     per lane, no atomics.
 // Per 32 directed edges: 84 chunk products and 56 chunk visits instead of 112 and 112, six LayerNorm / SiLU / operand-split phases
 // instead of eight.  What it costs: 4 x 4 tiles cover a complete graph of A atoms with (A - 1) / (4 * ceil((A - 1) / 4)) of their rows
 // at best (ti_api.hip: build_pair_template; 85 % for 18 atoms), and every atom's accumulators are touched from ~ (A - 1) / 4 blocks.
@@ -240,17 +240,34 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
             return QS::swap32_add(QS::swap16_add(v[0], v[1]), QS::swap16_add(v[2], v[3]));
         };
         // off: offset of the quantity inside a partial row (ds 0, dv (1 + c) F, c (4 + c) F) plus the lane's feature
-        auto emitA = [&](const f32x4& v0, const f32x4& v1, int off) {
-            const float z0 = sumA(v0), z1 = sumA(v1);
+        auto putA = [&](float z0, float z1, int off) {
             if (TI_PAIR_ACC_ATOMIC) { if (haveA) { float* d = acc_ptr(qnA, off); acc_out(d, z0, qfA); acc_out(d + 16, z1, qfA); } }
             else if (haveA) { partA[off] = z0; partA[off + 16] = z1; }
         };
-        // direction B: the four registers of a lane are the J slots of ONE destination I[q]
-        auto emitB = [&](const f32x4& v0, const f32x4& v1, int off) {
-            const float z0 = (v0[0] + v0[1]) + (v0[2] + v0[3]), z1 = (v1[0] + v1[1]) + (v1[2] + v1[3]);
+        auto putB = [&](float z0, float z1, int off) {
             if (TI_PAIR_ACC_ATOMIC) { if (haveB) { float* d = acc_ptr(qnB, off); acc_out(d, z0, qfB); acc_out(d + 16, z1, qfB); } }
             else if (haveB) { partB[off] = z0; partB[off + 16] = z1; }
         };
+        // direction B: the four registers of a lane are the J slots of ONE destination I[q]
+        auto sumB = [&](const f32x4& v) { return (v[0] + v[1]) + (v[2] + v[3]); };
+        auto emitA = [&](const f32x4& v0, const f32x4& v1, int off) { putA(sumA(v0), sumA(v1), off); };
+        auto emitB = [&](const f32x4& v0, const f32x4& v1, int off) { putB(sumB(v0), sumB(v1), off); };
+        // the value of lane row r' in every lane row, r' = 0 .. 3 (VALU lane swaps, mfma_chain.hpp)
+        auto rows4 = [&](float x, float (&o)[4]) {
+            float a = x, b = x;
+            lane_swap16(a, b);                       // a = [X0 X0 X2 X2], b = [X1 X1 X3 X3]
+            o[0] = a; o[2] = a; lane_swap32(o[0], o[2]);
+            o[1] = b; o[3] = b; lane_swap32(o[1], o[3]);
+        };
+        // v[src] rows of the equivariant slice.  Split path: every VMEM load of the slice is issued and consumed BEFORE its first accumulator
+        // atomic, and direction B's four source atoms J[r] are fetched once, by lane row r, and handed round with lane swaps.  Loads and
+        // writes share vmcnt but complete out of order with respect to each other, so waiting for a load while atomics are in flight
+        // costs `s_waitcnt vmcnt(0)`, the drain of those atomics -- with the gathers between the slice's atomics (three rounds per 32
+        // features) the launch took 29.60 ms, this way 28.23 (profiles/r03i_dv_reorder_timing.txt; the r03c stamps had shown the slice
+        // at 11 - 13 k cycles against 3 - 5 k for the others).  The f32 path is bound by its matrix instructions and short of registers:
+        // it keeps the gathers next to their use.
+        constexpr bool GATHER_EARLY = PREC != 0;
+        const long long nJq = snJ >= 0 ? node_of(slot_mol(snJ), snJ & 255) : nIq;   // J slot q's atom: lane row q fetches it for all four
         const float wrow = (meta & 1u) ? inv_out : 0.0f;                 // the same row factor in the row layout (lane (j, q): row j)
 
 #pragma unroll 1
@@ -296,39 +313,56 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
             {   // equivariant message: sum_e (sed * dir_e + gates * v[src_e]) -> dvacc ; sum_e cg * dir_e -> cacc
                 f32x4 sA0, sA1, sB0, sB1, gA0 = {0, 0, 0, 0}, gA1 = {0, 0, 0, 0}, gB0 = {0, 0, 0, 0}, gB1 = {0, 0, 0, 0};
                 out3(1, nbo, sA0, sA1, sB0, sB1);
-                float vA[3][2];                          // v[src] of direction A: one source atom I[q] for the lane's four rows
+                float vI[3][2], vJ[3][2];                // v of I[q] (source of direction A for the lane's four rows) and of J[q]
                 if (!FIRST) {
                     const float* vp = p.v + (size_t)nIq * 3 * F + fo;
+                    const float* vq = p.v + (size_t)nJq * 3 * F + fo;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { vA[c][0] = vp[c * F]; vA[c][1] = vp[c * F + 16]; }
+                    for (int c = 0; c < 3; ++c) {
+                        vI[c][0] = vp[c * F]; vI[c][1] = vp[c * F + 16];
+                        if (GATHER_EARLY) { vJ[c][0] = vq[c * F]; vJ[c][1] = vq[c * F + 16]; }
+                    }
                     out3(0, nbo, gA0, gA1, gB0, gB1);
                 }
                 f32x4 dir[4];                            // edge_dir of direction A; direction B's is its negative
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dir[r] = *reinterpret_cast<const f32x4*>(scratch + (4 * q + r) * 4);
+                float zA[3][2], zB[3][2];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     f32x4 v0, v1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v0[r] = sA0[r] * dir[r][c]; v1[r] = sA1[r] * dir[r][c];
-                        if (!FIRST) { v0[r] = fmaf(gA0[r], vA[c][0], v0[r]); v1[r] = fmaf(gA1[r], vA[c][1], v1[r]); }
+                        if (!FIRST) { v0[r] = fmaf(gA0[r], vI[c][0], v0[r]); v1[r] = fmaf(gA1[r], vI[c][1], v1[r]); }
                     }
-                    emitA(v0, v1, (1 + c) * F + fo);
+                    zA[c][0] = sumA(v0); zA[c][1] = sumA(v1);
+                    if (!GATHER_EARLY) putA(zA[c][0], zA[c][1], (1 + c) * F + fo);
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     f32x4 v0, v1;
+                    float j0[4], j1[4];                  // v[src] of direction B: the J atom of each row
+                    if (!FIRST) {
+                        if (GATHER_EARLY) { rows4(vJ[c][0], j0); rows4(vJ[c][1], j1); }
+                        else
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float* vr = p.v + (size_t)node_of(prow_molJ(mi[r]), prow_atomJ(mi[r])) * 3 * F + c * F + fo;
+                                j0[r] = vr[0]; j1[r] = vr[16];
+                            }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v0[r] = -(sB0[r] * dir[r][c]); v1[r] = -(sB1[r] * dir[r][c]);
-                        if (!FIRST) {                    // v[src] of direction B: the J atom of each row
-                            const float* vp = p.v + (size_t)node_of(prow_molJ(mi[r]), prow_atomJ(mi[r])) * 3 * F + c * F + fo;
-                            v0[r] = fmaf(gB0[r], vp[0], v0[r]); v1[r] = fmaf(gB1[r], vp[16], v1[r]);
-                        }
+                        if (!FIRST) { v0[r] = fmaf(gB0[r], j0[r], v0[r]); v1[r] = fmaf(gB1[r], j1[r], v1[r]); }
                     }
-                    emitB(v0, v1, (1 + c) * F + fo);
+                    zB[c][0] = sumB(v0); zB[c][1] = sumB(v1);
+                    if (!GATHER_EARLY) putB(zB[c][0], zB[c][1], (1 + c) * F + fo);
                 }
+                if (GATHER_EARLY)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { putA(zA[c][0], zA[c][1], (1 + c) * F + fo); putB(zB[c][0], zB[c][1], (1 + c) * F + fo); }
                 TI_STAMP();
                 if (!FIRST) {
                     f32x4 cA0, cA1, cB0, cB1;
