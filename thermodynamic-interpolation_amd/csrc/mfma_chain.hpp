@@ -992,12 +992,19 @@ template <int NBK>
 __device__ __forceinline__ void gemm_fl(f32x4& acc0, f32x4& acc1, const OpndH<NBK>& in, const f32x4* wl4, int lane) { gemm_half_chunk<NBK, true>(acc0, acc1, in, reinterpret_cast<const h8*>(wl4), lane); }
 
 // product of the pipe's current chunk with operand set `in` (FLIP: features on lanes).  The caller releases the chunk.
+// The product runs at raised issue priority (s_setprio): the wave's matrix instructions go ahead of the SIMD partner's vector work --
+// LayerNorm, operand splits, the output stage's sums -- which fills the slots in between instead of delaying them.  Measured on the
+// pair-major message kernel: 28.13 -> 27.33 ms, levels 1, 2, 3 alike; directed layout 31.24 -> 31.03 (profiles/r03i_setprio_timing.txt).
+// (Only here and in gemm_x2_on_pipe, i.e. in the message kernels: s_setprio is a scheduling boundary for hipcc, and placed in the
+// pipe's acquire / release it cost the tangent edge kernel 680 spilled registers.)
 template <bool FLIP, class OP, class PIPE>
 __device__ __forceinline__ void gemm_on_pipe(f32x4& acc0, f32x4& acc1, const OP& in, PIPE& pipe, int lane)
 {
     const f32x4* wl = pipe.acquire();
+    __builtin_amdgcn_s_setprio(1);
     if constexpr (FLIP) gemm_fl(acc0, acc1, in, wl, lane);
     else gemm_bt(acc0, acc1, in, wl, lane);
+    __builtin_amdgcn_s_setprio(0);
 }
 // An operand set as the 16-byte registers it is made of, parked in / fetched from HBM in register order ([register][lane]: every
 // instruction moves 1 KB contiguous).  dst / src already point at this lane's slot.
@@ -1236,7 +1243,10 @@ __device__ __forceinline__ void gemm_x2(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& 
 template <bool FLIP, class OP, class PIPE>
 __device__ __forceinline__ void gemm_x2_on_pipe(f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, const OP& inA, const OP& inB, PIPE& pipe, int lane)
 {
-    gemm_x2<FLIP>(a0, a1, b0, b1, inA, inB, pipe.acquire(), lane);
+    const f32x4* wl = pipe.acquire();
+    __builtin_amdgcn_s_setprio(1);                  // see gemm_on_pipe
+    gemm_x2<FLIP>(a0, a1, b0, b1, inA, inB, wl, lane);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 }  // namespace r16

@@ -356,6 +356,10 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
         const f32x4* wq = reinterpret_cast<const f32x4*>(p.wq) + ((size_t)(pg * p.nblk + blk) * 5 * NB) * 6 * 64 + lane;
         // value and tangent of (phi_c + b)(w_c + b) for output chunk c, 32 features as two 16-feature blocks
         auto out_pair = [&](int c, int nbo, f32x4& r0, f32x4& r1, f32x4& d0, f32x4& d1) {
+            // raised issue priority from the filter-product loads to the tangent products (mfma_chain.hpp: gemm_on_pipe): +1.5 % on the
+            // divergence workload (profiles/r03i_setprio_timing.txt); around the hidden layers' products it changes nothing, and bracketing
+            // only the matrix instructions here costs hipcc 680 spilled registers (s_setprio is a scheduling boundary)
+            __builtin_amdgcn_s_setprio(1);
             const f32x4* g = wq + (size_t)(c * NB + nbo) * 6 * 64;
             const f32x4 A0 = g[0], A1 = g[64], B0 = g[128], B1 = g[192], Q0 = g[256], Q1 = g[320];
             f32x4 ta0 = Z4, ta1 = Z4;
@@ -364,6 +368,7 @@ __global__ __launch_bounds__(256, (NBK <= 8 ? 2 : 1)) void painn_jvp_edge_kernel
             pipe.release();
             r0 = A0 * B0; r1 = A1 * B1;
             d0 = ta0 * B0 + A0 * (dd * Q0); d1 = ta1 * B1 + A1 * (dd * Q1);
+            __builtin_amdgcn_s_setprio(0);
         };
         auto emit = [&](const f32x4& v0, const f32x4& v1, float* dst, size_t stride) {
             const float z0 = qs.sum(v0), z1 = qs.sum(v1);
