@@ -4,7 +4,7 @@
     python tools/variant_bench.py build  TAG[:FLAGS] ...     # here (cross-compile): thermodynamic-interpolation_amd/build/variants/libti_hip_TAG.so
     python tools/variant_bench.py run [--batch B] [--steps K] [--rounds R] [--precision f16x2] TAG ...     # on the GPU box
 
-FLAGS are extra hipcc flags, '+'-separated (e.g. nopk:-Xclang+-target-feature+-Xclang+-packed-fp32-ops, x:-DTI_SOMETHING=1);
+FLAGS are extra hipcc flags, '+'-separated (e.g. pk:-Xclang+-target-feature+-Xclang++packed-fp32-ops, x:-DTI_SOMETHING=1), appended to the product's own (build.py);
 ONLY=file.hip restricts recompilation to that source (the product objects of the others are linked).
 TAG `base` means the product library; `TAG@LAYOUT` (run only) pins the edge-row layout of that arm (throughput | latency | pair;
 default: TI_VB_TEMPLATE or throughput), e.g. `base@throughput base@pair`.  `run` starts one child process per (round, tag), interleaved, so that clock and box
@@ -23,6 +23,17 @@ PKG = os.path.join(ROOT, "thermodynamic-interpolation_amd")
 VDIR = os.path.join(PKG, "build", "variants")
 SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_nb2.hip", "painn_edge_nb4.hip", "painn_edge_nb8.hip",
            "painn_pair_nb1.hip", "painn_pair_nb2.hip", "painn_pair_nb4.hip", "painn_jvp_kernels.hip", "adw_kernels.hip", "ode_kernels.hip"]
+
+
+def _load_build():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ti_build", os.path.join(PKG, "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+BUILD = _load_build()
 
 
 def lib_of(tag):
@@ -46,7 +57,7 @@ def build(specs):
                 return os.path.join(PKG, "build", src.replace(".hip", ".o"))
             obj = os.path.join(objdir, src.replace(".hip", ".o"))
             csrc = os.environ.get("TI_VARIANT_SRC") or os.path.join(PKG, "csrc")       # e.g. an extracted `git archive` of another commit
-            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *flags, "-c", os.path.join(csrc, src), "-o", obj])
+            subprocess.check_call(["hipcc", *BUILD.FLAGS, *BUILD.EXTRA_FLAGS.get(src, []), *flags, "-c", os.path.join(csrc, src), "-o", obj])      # the product's flags + the variant's
             return obj
         with ThreadPoolExecutor(max_workers=8) as ex:
             objs = list(ex.map(one, SOURCES))
