@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TI_ABI_VERSION 4
+#define TI_ABI_VERSION 5
 
 enum { TI_OK = 0, TI_E_ARG = -1, TI_E_HIP = -2, TI_E_NAN = -3, TI_E_ALLOC = -4, TI_E_UNSUPPORTED = -5 };
 enum { TI_MEM_HOST = 0, TI_MEM_DEVICE = 1 };
@@ -215,6 +215,11 @@ int ti_profile_read(ti_handle* h, int kernel, int64_t* n_launches, double* total
  * 3, 4, 5 = the tangents of s, v, e of the last ti_painn_drift_jvp call, same shapes. */
 int ti_painn_debug_tap(ti_handle* h, int stop_after_stage);   /* stage = 0 embed, 1+2l message l, 2+2l update l; -1 = off */
 int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats);
+/* Test hook for the first-touch accumulators (csrc/painn_edge_kernel.hpp: acc_out): fill the per-atom accumulators dsacc / dvacc / cacc of
+ * the workspace for B trajectories with `value` (NaN, 1e30 ...) on the handle's stream.  A following ti_painn_drift must return exactly what
+ * a handle created with TI_ZERO_ACC=1 in the environment (zeroing path: memsets + adds only) returns.  Reference counterpart: none
+ * (torch_scatter allocates its output, cpainn.py:303-304). */
+int ti_painn_debug_poison(ti_handle* h, int64_t B, float value);
 /* Device self-test of the MFMA operand/accumulator lane maps the kernels rely on, of both fp32 -> (hi, lo) fp16 operand splits
  * (the 8-instruction forms of formats (a) and (b) against the plain arithmetic, bit for bit, fp16-subnormal residuals included),
  * and of the fp16 matrix instruction keeping subnormal inputs. */

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert sorted(ti._lib.ABI_SYMBOLS) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ti_version() == 4          # TI_ABI_VERSION 4: v3 (step_offset, ti_wait_stream, ti_set_stream(mode), template pin) + TI_TEMPLATE_PAIR
+    assert lib.ti_version() == 5          # TI_ABI_VERSION 5: v4 (TI_TEMPLATE_PAIR) + ti_painn_debug_poison
 
 
 def test_rollout_rows_matches_oracle_definition(lib):

@@ -175,3 +175,42 @@ def test_pair_race_screen_full_occupancy(monkeypatch):
     orc = oracle.PainnOracle(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0)
     idx = np.r_[0:3, B - 3:B]
     assert rel_l2(outs["f16x2"][idx].reshape(-1, A, 3), orc.drift(x[idx], 0.5, cond[idx], precision=64)) < DRIFT_TOL
+
+
+@pytest.mark.parametrize("layout", ["pair", "throughput"])
+@pytest.mark.parametrize("poison", [float("nan"), 1e30])
+def test_first_touch_accumulators_ignore_stale_contents(monkeypatch, layout, poison):
+    """First-touch accumulators (csrc/painn_edge_kernel.hpp: acc_out; nothing zeroes dsacc / dvacc / cacc between layers or calls): with the
+    accumulators POISONED before the evaluation (NaN, 1e30), at full occupancy and 18 atoms (every atom is touched from several row blocks,
+    by different lanes of its wave), both layouts must return exactly what the zeroing path returns (TI_ZERO_ACC=1: memsets, the update
+    kernel clears what it consumed, adds only).  The hardware property this rests on: no-return atomics of ONE wave to ONE address reach
+    L2 in program order (exchange of block b before the adds of block b + 1), DESIGN.md 3.1."""
+    ti = pkg()
+    syn, W = ti.synthetic, ti.weights
+    F, L, A, B = 128, 5, 18, 16384
+    src, dst, et = syn.fully_connected_template(A)
+    flat = W.flatten_state_dict(syn.painn_state_dict(0, F, L, 25, seed=0), W.painn_param_spec(0, F, L, 25))
+    x, cond = syn.molecule_coords(B, A, seed=0), syn.ambient_cond(B, A)
+
+    def run(zeroing):
+        if zeroing:
+            monkeypatch.setenv("TI_ZERO_ACC", "1")
+        else:
+            monkeypatch.delenv("TI_ZERO_ACC", raising=False)
+        eng = ti.engine.PainnEngine(0, F, L, A, src, dst, et, np.arange(A), flat, temp_length=100.0, precision="f16x2")
+        monkeypatch.delenv("TI_ZERO_ACC", raising=False)
+        eng.set_template(layout)
+        outs = []
+        for _ in range(2):                                   # the second call meets the first one's leftovers as well
+            if not zeroing:
+                eng.debug_poison(B, poison)
+            outs.append(eng.drift(x, 0.5, cond))
+        eng.close()
+        return outs
+
+    ref = run(True)
+    got = run(False)
+    assert np.isfinite(ref[0]).all()
+    for g in got:
+        np.testing.assert_array_equal(g, ref[0])
+    np.testing.assert_array_equal(ref[1], ref[0])

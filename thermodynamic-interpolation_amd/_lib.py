@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "ti_adw_create", "ti_adw_drift", "ti_adw_drift_div", "ti_adw_rollout", "ti_adw_rollout_dlogp",
     "ti_painn_create", "ti_painn_drift", "ti_painn_rollout", "ti_painn_drift_jvp", "ti_painn_drift_div", "ti_painn_rollout_dlogp",
     "ti_destroy", "ti_set_stream", "ti_wait_stream", "ti_painn_set_template", "ti_painn_template_for", "ti_reserve", "ti_profile_enable", "ti_profile_read",
-    "ti_painn_debug_tap", "ti_painn_debug_read", "ti_selftest",
+    "ti_painn_debug_tap", "ti_painn_debug_read", "ti_painn_debug_poison", "ti_selftest",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
     L.ti_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.ti_painn_debug_tap.argtypes = [vp, C.c_int]
     L.ti_painn_debug_read.argtypes = [vp, C.c_int, fp, C.c_size_t]
+    L.ti_painn_debug_poison.argtypes = [vp, C.c_int64, C.c_float]
     L.ti_selftest.argtypes = [C.c_int]
     _lib = L
     return L

@@ -288,6 +288,9 @@ void build_templates(ti_handle* h, const int32_t* src, const int32_t* dst, const
         std::vector<char> has_in(A, 0);
         for (int k = 0; k < E; ++k) has_in[dst[k]] = 1;
         h->first_touch = E > 0 && std::all_of(has_in.begin(), has_in.end(), [](char c) { return c != 0; });
+        // triage switch: TI_ZERO_ACC=1 at creation forces the zeroing path (memsets before an evaluation, the update kernel clears
+        // what it consumed, every accumulator update is an add) -- tests/test_gpu_pair.py compares the two paths on poisoned accumulators
+        if (const char* z = std::getenv("TI_ZERO_ACC")) if (z[0] == '1') h->first_touch = false;
     }
     h->perm.resize(E);
     for (int k = 0; k < E; ++k) h->perm[k] = k;
@@ -1378,6 +1381,21 @@ int ti_painn_debug_tap(ti_handle* h, int stage)
     if (h->d.precision == TI_PREC_F16 && stage >= 0) return fail(TI_E_UNSUPPORTED, "debug taps read fp32 state; not available in the fp16 storage mode");
     h->tap = stage;
     return TI_OK;
+}
+
+int ti_painn_debug_poison(ti_handle* h, int64_t B, float value)
+{
+    if (!h || h->kind != 0 || B <= 0) return fail(TI_E_ARG, "not a painn handle / B");
+    return guarded([&]() -> int {
+        set_device(h);
+        ensure_painn_ws(h, B);
+        const size_t N = (size_t)B * h->d.n_atoms, F = h->d.n_features;
+        const unsigned bits = __builtin_bit_cast(unsigned, value);
+        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)h->dsacc.p, (int)bits, N * F, h->stream));
+        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)h->dvacc.p, (int)bits, N * 3 * F, h->stream));
+        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)h->cacc.p, (int)bits, N * 3 * F, h->stream));
+        return TI_OK;
+    });
 }
 
 int ti_painn_debug_read(ti_handle* h, int what, float* out, size_t n_floats)

@@ -225,6 +225,10 @@ class PainnEngine(_Engine):
     def debug_tap(self, stage: int):
         _lib.check(_lib.lib().ti_painn_debug_tap(self.h, int(stage)))
 
+    def debug_poison(self, B: int, value: float):
+        """Test hook: fill the per-atom accumulators of the workspace for B molecules with `value` (first-touch test)."""
+        _lib.check(_lib.lib().ti_painn_debug_poison(self.h, int(B), float(value)))
+
     def debug_read(self, what: str, B: int):
         """what: 's' | 'v' | 'e', or 'ts' | 'tv' | 'te' for the tangents of the last jvp() call."""
         shape = {"s": (B, self.A, self.F), "v": (B, self.A, 3, self.F), "e": (B, self.E, self.F)}[what[-1]]
