@@ -14,7 +14,7 @@ SOURCES = ["ti_api.hip", "painn_kernels.hip", "painn_edge_nb1.hip", "painn_edge_
 HEADERS = ["mfma_chain.hpp", "ti_internal.hpp", "painn_edge_kernel.hpp", "painn_pair_kernel.hpp", "pair_template.hpp", os.path.join("..", "..", "include", "ti_hip.h")]
 # -packed-fp32-ops off: v_pk_{fma,mul,add}_f32 do NOT run next to another wave's matrix instructions on gfx950 (a wave of them and a
 # wave of 16x16x32 fp16 MFMAs on one SIMD take the SUM of their times; scalar v_fma_f32, conversions and transcendentals overlap:
-# tools/microbench_coexec.hip, profiles/r03i_microbench_coexec.txt), and register pairs cost the message kernels registers (pair
+# tools/micro/coexec_classes.hip, profiles/r03i_microbench_coexec.txt), and register pairs cost the message kernels registers (pair
 # kernel: 19 -> 4 spilled).  Measured, same box: pair message kernel -2.0 %, directed -0.6 %, divergence workload +1.2 %
 # (profiles/r03i_nopk_timing.txt); results move in the last bit (fma contraction), parity unchanged.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]

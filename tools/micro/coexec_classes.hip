@@ -1,6 +1,6 @@
-// microbench_coexec.hip -- do matrix (MFMA) and vector (VALU) instructions of TWO waves on one SIMD overlap on gfx950, or only
+// coexec_classes.hip (round 3; coexec.hip is the round-2 scalar-fma version) -- do matrix (MFMA) and vector (VALU) instructions of TWO waves on one SIMD overlap on gfx950, or only
 // within one wave's own instruction stream?  (the message kernels' two waves per SIMD add up instead of overlapping.)
-//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o thermodynamic-interpolation_amd/build/coexec tools/microbench_coexec.hip   (here), then on the GPU box: thermodynamic-interpolation_amd/build/coexec
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o tools/micro/coexec_classes tools/micro/coexec_classes.hip   (here), then on the GPU box: tools/micro/coexec_classes
 // One 512-thread workgroup per CU (LDS-padded): waves w and w + 4 share a SIMD.  Roles by wave index:
 //   mode 0: waves 0-3 issue N fp16 16x16x32 MFMAs (chains of 3 on one accumulator, like the split products), waves 4-7 exit
 //   mode 1: waves 4-7 issue V dependent-free v_fma_f32, waves 0-3 exit
