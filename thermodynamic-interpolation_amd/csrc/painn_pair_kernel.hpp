@@ -274,17 +274,11 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
         for (int nbo = 0; nbo < NB; ++nbo) {
             const int fo = 32 * nbo + j;
             TI_STAMP();
-            float zdA0, zdA1, zdB0, zdB1;
             {   // ds: invariant message, summed over incoming edges
                 f32x4 a0, a1, b0, b1;
                 out3(2, nbo, a0, a1, b0, b1);
-#ifdef TI_PAIR_DS_LATE
-                zdA0 = sumA(a0); zdA1 = sumA(a1); zdB0 = sumB(b0); zdB1 = sumB(b1);
-                if (LAST) { putA(zdA0, zdA1, fo); putB(zdB0, zdB1, fo); }
-#else
                 emitA(a0, a1, fo);
                 emitB(b0, b1, fo);
-#endif
             }
             TI_STAMP();
             if constexpr (!LAST) {
@@ -314,9 +308,6 @@ __global__ __launch_bounds__(64 * WAVES, 2 * 4 / WAVES) void painn_pair_kernel(c
                     r16::store_block(ea, 2 * nbo, q, oA0 + a0 * w0); r16::store_block(ea, 2 * nbo + 1, q, oA1 + a1 * w1);
                     r16::store_block(eb, 2 * nbo, q, oB0 + b0 * w0); r16::store_block(eb, 2 * nbo + 1, q, oB1 + b1 * w1);
                 }
-#ifdef TI_PAIR_DS_LATE
-                putA(zdA0, zdA1, fo); putB(zdB0, zdB1, fo);
-#endif
             }
             TI_STAMP();
             {   // equivariant message: sum_e (sed * dir_e + gates * v[src_e]) -> dvacc ; sum_e cg * dir_e -> cacc
