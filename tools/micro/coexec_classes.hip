@@ -195,6 +195,62 @@ __global__ __launch_bounds__(512, 1) void coexec_cls(int cls, int with_mfma, flo
     if (r == 12345.678f) sink[threadIdx.x] = r + pad[threadIdx.x];
 }
 
+// ---- closer to the message kernel: the matrix wave reads its B fragments from LDS (two ds_read_b128 per six MFMAs, one step ahead,
+// waited for with lgkmcnt), the vector wave runs a LayerNorm-like mix (per 32 instructions: 16 fma, 4 exp, 4 rcp, 4 cvt_pk, 4 fma_mix)
+__device__ __forceinline__ f32x4 mfma_lds_loop(const h8* frag, int lane, h8 a, f32x4 acc)
+{
+    f32x4 c0 = acc, c1 = acc;
+    h8 f0 = frag[lane], f1 = frag[64 + lane];
+    for (int i = 0; i < 2 * ITER; ++i) {
+        const int nx = ((i + 1) & 63) * 128;
+        const h8 n0 = frag[nx + lane], n1 = frag[nx + 64 + lane];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, f0, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, a, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, f0, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, f1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, f1, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, a, c1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = n0; f1 = n1;
+    }
+    return c0 + c1;
+}
+__device__ __forceinline__ float mix_loop(float x, float y)
+{
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = x + 0.01f * k;
+    for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            asm volatile("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(v[k]), "+v"(v[k + 1]) : "v"(y), "v"(x));
+            asm volatile("v_exp_f32 %0, %0\n\tv_rcp_f32 %1, %1" : "+v"(v[k]), "+v"(v[k + 1]));
+            asm volatile("v_cvt_pk_f16_f32 %0, %0, %1\n\tv_fma_mixlo_f16 %1, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(v[k]), "+v"(v[k + 1]) : "v"(y));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+    return s;
+}
+__global__ __launch_bounds__(512, 1) void coexec_lds(int mode, float* sink, float x, float y)
+{
+    extern __shared__ float pad[];
+    h8* frag = reinterpret_cast<h8*>(pad);
+    for (int i = threadIdx.x; i < 64 * 128; i += 512) { h8 t; for (int k = 0; k < 8; ++k) t[k] = (_Float16)(0.001f * ((i + k) & 15)); frag[i] = t; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool lo = wave < 4;
+    h8 a;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (_Float16)(x + k);
+    f32x4 acc = {x, y, x, y};
+    float r = 0;
+    // 0: LDS-fed matrix waves only; 1: mix waves only; 2: both; 3: both, matrix wave at priority 1; 4: two LDS-fed matrix waves; 5: two mix waves
+    const bool do_m = mode == 4 || ((mode == 0 || mode == 2 || mode == 3) && lo);
+    const bool do_v = mode == 5 || ((mode == 1 || mode == 2 || mode == 3) && !lo);
+    if (do_m) { if (mode == 3) __builtin_amdgcn_s_setprio(1); f32x4 o = mfma_lds_loop(frag, lane, a, acc); r = o[0] + o[1] + o[2] + o[3]; }
+    else if (do_v) r = mix_loop(x, y);
+    if (r == 12345.678f) sink[threadIdx.x] = r;
+}
+
 int main()
 {
     float* sink;
@@ -235,6 +291,22 @@ int main()
             t[w] = best;
         }
         printf("  %-44s %8.3f ms | %8.3f ms\n", cls[c], t[0], t[1]);
+    }
+    hipFuncSetAttribute((const void*)coexec_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    const char* ln[] = {"LDS-fed matrix waves only (12 MFMA + 4 ds_read_b128 per iteration)", "LayerNorm-like vector waves only (16 fma, 4 exp, 4 rcp, 4 cvt_pk, 4 fma_mix)",
+                        "LDS-fed matrix wave + LayerNorm-like wave", "the same, matrix wave at s_setprio 1", "two LDS-fed matrix waves", "two LayerNorm-like waves"};
+    printf("closer to the message kernel:\n");
+    for (int mode = 0; mode < 6; ++mode) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(coexec_lds, dim3(256), dim3(512), 140 * 1024, 0, mode, sink, 1.0f, 0.5f);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep && ms < best) best = ms;
+        }
+        printf("  lds mode %d  %-84s %8.3f ms\n", mode, ln[mode], best);
     }
     if (hipGetLastError() != hipSuccess) { printf("HIP error\n"); return 1; }
     return 0;
