@@ -212,6 +212,29 @@ __device__ __forceinline__ f32x4 mfma_lds_loop(const h8* frag, int lane, h8 a, f
     }
     return c0 + c1;
 }
+// the same FLOPs on v_mfma_f32_32x32x16_f16: two fragments feed three instructions (hi.hi, lo.hi, hi.lo of one 32 x 32 tile), two tiles in flight
+__device__ __forceinline__ f32x16 mfma32_lds_loop(const h8* frag, int lane, h8 a, float x)
+{
+    f32x16 c0, c1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { c0[k] = x + k; c1[k] = x - k; }
+    h8 f0 = frag[lane], f1 = frag[64 + lane];
+    for (int i = 0; i < ITER; ++i) {
+        const int nx = ((2 * i + 1) & 63) * 128, ny = ((2 * i + 2) & 63) * 128;
+        const h8 n0 = frag[nx + lane], n1 = frag[nx + 64 + lane];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, f0, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, f0, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, f1, c0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const h8 m0 = frag[ny + lane], m1 = frag[ny + 64 + lane];
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, n0, c1, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(n1, n0, c1, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, n1, c1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        f0 = m0; f1 = m1;
+    }
+    return c0 + c1;
+}
 __device__ __forceinline__ float mix_loop(float x, float y)
 {
     float v[8];
@@ -244,6 +267,14 @@ __global__ __launch_bounds__(512, 1) void coexec_lds(int mode, float* sink, floa
     f32x4 acc = {x, y, x, y};
     float r = 0;
     // 0: LDS-fed matrix waves only; 1: mix waves only; 2: both; 3: both, matrix wave at priority 1; 4: two LDS-fed matrix waves; 5: two mix waves
+    // 6 / 7 / 8: as 0 / 2 / 4 with the 32x32x16 instruction
+    if (mode >= 6) {
+        const bool m32 = mode == 8 || lo;
+        if (m32) { f32x16 o = mfma32_lds_loop(frag, lane, a, x); for (int k = 0; k < 16; ++k) r += o[k]; }
+        else if (mode == 7) r = mix_loop(x, y);
+        if (r == 12345.678f) sink[threadIdx.x] = r;
+        return;
+    }
     const bool do_m = mode == 4 || ((mode == 0 || mode == 2 || mode == 3) && lo);
     const bool do_v = mode == 5 || ((mode == 1 || mode == 2 || mode == 3) && !lo);
     if (do_m) { if (mode == 3) __builtin_amdgcn_s_setprio(1); f32x4 o = mfma_lds_loop(frag, lane, a, acc); r = o[0] + o[1] + o[2] + o[3]; }
@@ -294,9 +325,10 @@ int main()
     }
     hipFuncSetAttribute((const void*)coexec_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     const char* ln[] = {"LDS-fed matrix waves only (12 MFMA + 4 ds_read_b128 per iteration)", "LayerNorm-like vector waves only (16 fma, 4 exp, 4 rcp, 4 cvt_pk, 4 fma_mix)",
-                        "LDS-fed matrix wave + LayerNorm-like wave", "the same, matrix wave at s_setprio 1", "two LDS-fed matrix waves", "two LayerNorm-like waves"};
+                        "LDS-fed matrix wave + LayerNorm-like wave", "the same, matrix wave at s_setprio 1", "two LDS-fed matrix waves", "two LayerNorm-like waves",
+                        "LDS-fed 32x32x16 matrix waves only (6 MFMA + 4 ds_read_b128 per iteration: the same FLOPs and bytes)", "LDS-fed 32x32x16 matrix wave + LayerNorm-like wave", "two LDS-fed 32x32x16 matrix waves"};
     printf("closer to the message kernel:\n");
-    for (int mode = 0; mode < 6; ++mode) {
+    for (int mode = 0; mode < 9; ++mode) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(e0);
