@@ -32,10 +32,12 @@
 namespace ti {
 
 __host__ __device__ constexpr bool pair_build_exists(int NB, int WAVES, int PREC) { return PREC != 2 && NB <= 4 && (WAVES == 4 || WAVES == 8); }
-// weight ring (mfma_chain.hpp PipeDMA): 2-chunk superchunks; the 8-wave build (one workgroup per CU) keeps four of them, i.e. requests
-// the stream three superchunks ahead (128 KB at F = 128), the 4-wave build (two workgroups per CU) two
+// weight ring (mfma_chain.hpp PipeDMA): 2-chunk superchunks, two of them (64 KB at F = 128) in both builds.  A deeper ring (the stream
+// requested three superchunks ahead: TI_PAIR_NBUF = 4, the round's first choice) buys nothing -- every superchunk barrier drains the
+// wave's memory queue anyway as soon as a store or an atomic is in flight -- and its index arithmetic cost the
+// last-layer kernel 31 spilled registers: 26.16 ms with two buffers against 26.48 with four, same box (profiles/r03l_ring_depth.txt).
 #ifndef TI_PAIR_NBUF
-#define TI_PAIR_NBUF 4
+#define TI_PAIR_NBUF 2
 #endif
 __host__ __device__ constexpr int pair_superchunk() { return 2; }
 __host__ __device__ constexpr int pair_ring(int WAVES) { return WAVES == 8 ? TI_PAIR_NBUF : 2; }
